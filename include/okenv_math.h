@@ -1,0 +1,160 @@
+/*
+ * okenv_math.h -- scalar math shared, bit for bit, by the HIP kernels and the CPU oracle.
+ *
+ * Why this exists (SURVEY.md section 0 item 5, section 7 "Transcendentals"): the reference's host
+ * code calls glibc cosf/sinf (Environment/Agent.cpp:94-97,115-118, Environment/CollisionChecker.cu:
+ * 121-124,157-158) and its kernel calls CUDA cosf/sinf (Environment/CollisionChecker.cu:47-48).
+ * Those differ from each other and from ROCm's OCML in the last ulp, which is enough to flip the
+ * `min_dist2 < 2.0f` crash test.  Crash/done flags must be bit-exact between the GPU path and the
+ * CPU oracle, so both sides evaluate sine/cosine through THIS header: an fp64 Cody-Waite reduction and
+ * an fp64 Taylor polynomial, rounded once to fp32.  Only +,-,* and round-to-nearest-even conversions are
+ * used, all IEEE-exact on x86-64 and on gfx950, so the two sides agree bit for bit provided the
+ * translation unit is compiled with -ffp-contract=off (no FMA contraction).
+ * tests/test_math.py bounds the distance to glibc sincosf (<= 1 ulp) and to an fp64 reference.
+ *
+ * Also here: Philox4x32-10 (Salmon et al., SC'11), the counter-based generator the C2 bench recipe
+ * draws actions and reset positions from, so the device rollout and the oracle
+ * rollout see identical streams.
+ *
+ * Plain C99 / C++ / HIP.  No dependency on anything under oracle/.
+ */
+#ifndef OKENV_MATH_H
+#define OKENV_MATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define OK_HD __host__ __device__ static inline
+#else
+#define OK_HD static inline
+#endif
+
+/* Environment/Typedefs.h:10  kDeg2Rad = float(M_PI / 180.0F)  (bit pattern 0x3C8EFA35) */
+#define OK_DEG2RAD 0.01745329238474369049072265625f
+/* Environment/Agent.cpp:84,110  kDt{0.016} as float (bit pattern 0x3C83126F) */
+#define OK_DT 0.016000000759959220886230468750f
+/* Environment/Agent.h:10-11 */
+#define OK_SENSOR_RANGE 200.0f
+#define OK_SPEED_LIMIT 100.0f
+/* Environment/CollisionChecker.cu:167 */
+#define OK_CRASH_DIST2 2.0f
+/* Environment/Environment.h:19-20 */
+#define OK_DISP_PERIOD 200u
+#define OK_DISP_THRESH2 400.0f /* kDisplamentThreshold^2 = 20*20, exact in fp32 */
+/* Environment/CollisionChecker.cu:23 */
+#define OK_PARALLEL_EPS 1e-8f
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OK_RINT(x) __builtin_rint(x)
+#else
+#define OK_RINT(x) __builtin_rint(x)
+#endif
+
+/*
+ * sin and cos of an fp32 angle [rad], each correctly rounded from an fp64 evaluation whose error is
+ * < 1e-15 for |x| < 1.6e6 rad (9e7 degrees; rot_ is never wrapped, Environment/Agent.cpp:86,112, so
+ * large arguments do occur).  Beyond that the reduction loses accuracy gracefully but stays
+ * deterministic and identical on both sides; NaN/Inf give NaN.
+ */
+OK_HD void ok_sincosf(float x, float *s_out, float *c_out)
+{
+    const double xd = (double)x;
+    /* q = nearest integer to x * 2/pi */
+    const double q = OK_RINT(xd * 0.63661977236758138243);
+    /* pi/2 split in three parts; the first two carry 33 significant bits each, so q*P1 and q*P2 are
+     * exact products for |q| < 2^20. */
+    const double P1 = 1.57079632673412561417e+00;
+    const double P2 = 6.07710050630396597660e-11;
+    const double P3 = 2.02226624879595063154e-21;
+    double r = xd - q * P1;
+    r = r - q * P2;
+    r = r - q * P3;
+    /* quadrant = q mod 4, taken in fp64 so that no out-of-range float->int conversion can happen */
+    const double qm = q - 4.0 * OK_RINT(q * 0.25); /* in {-2,-1,0,1,2} */
+    const int n = ((int)qm) & 3;
+    const double z = r * r;
+    /* Taylor series; |r| <= pi/4 so the truncation error is < 5e-17 (sin) and < 1e-15 (cos). */
+    double ps = -7.647163731819816475901131985788070444155e-13; /* -1/15! */
+    ps = ps * z + 1.605904383682161459939237717015494793273e-10; /*  1/13! */
+    ps = ps * z - 2.505210838544171877505210838544171877505e-08; /* -1/11! */
+    ps = ps * z + 2.755731922398589065255731922398589065256e-06; /*  1/9!  */
+    ps = ps * z - 1.984126984126984126984126984126984126984e-04; /* -1/7!  */
+    ps = ps * z + 8.333333333333333333333333333333333333333e-03; /*  1/5!  */
+    ps = ps * z - 1.666666666666666666666666666666666666667e-01; /* -1/3!  */
+    const double sr = r + r * (z * ps);
+    double pc = -1.147074559772972471385169797868210566623e-11; /* -1/14! */
+    pc = pc * z + 2.087675698786809897921009032120143231254e-09; /*  1/12! */
+    pc = pc * z - 2.755731922398589065255731922398589065256e-07; /* -1/10! */
+    pc = pc * z + 2.480158730158730158730158730158730158730e-05; /*  1/8!  */
+    pc = pc * z - 1.388888888888888888888888888888888888889e-03; /* -1/6!  */
+    pc = pc * z + 4.166666666666666666666666666666666666667e-02; /*  1/4!  */
+    pc = pc * z - 0.5;                                            /* -1/2!  */
+    const double cr = 1.0 + z * pc;
+    double sv, cv;
+    if (n == 0) { sv = sr; cv = cr; }
+    else if (n == 1) { sv = cr; cv = -sr; }
+    else if (n == 2) { sv = -sr; cv = -cr; }
+    else { sv = -cr; cv = sr; }
+    *s_out = (float)sv;
+    *c_out = (float)cv;
+}
+
+/* ---- Philox4x32-10 -------------------------------------------------------------------------- */
+
+typedef struct ok_u32x4 { uint32_t v[4]; } ok_u32x4;
+
+OK_HD ok_u32x4 ok_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+    for (int round = 0; round < 10; ++round) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    ok_u32x4 r;
+    r.v[0] = c0; r.v[1] = c1; r.v[2] = c2; r.v[3] = c3;
+    return r;
+}
+
+/* u32 -> [0,1) with 24 random bits; every step is exact in fp32 */
+OK_HD float ok_u01(uint32_t u)
+{
+    return (float)(u >> 8) * 5.9604644775390625e-08f; /* 2^-24 */
+}
+
+/*
+ * The C2 synthetic-action recipe:
+ *   counter = (agent, step, 0, 0), key = (seed, 0x6F6B656E /"oken"/)
+ *   throttle = U[0,100), steer = U[-5,5), reset_idx = floor(U * P) drawn from the third word.
+ * `agent` is the GLOBAL agent id, so a population sharded over ranks reproduces the unsharded streams.
+ */
+typedef struct ok_random_action { float throttle; float steer; uint32_t reset_word; } ok_random_action;
+
+OK_HD ok_random_action ok_draw_random_action(uint32_t seed, uint32_t agent, uint32_t step)
+{
+    const ok_u32x4 r = ok_philox4x32(agent, step, 0u, 0u, seed, 0x6F6B656Eu);
+    ok_random_action a;
+    a.throttle = ok_u01(r.v[0]) * 100.0f;
+    a.steer = ok_u01(r.v[1]) * 10.0f - 5.0f;
+    a.reset_word = r.v[2];
+    return a;
+}
+
+/* index in [0,P) from a 32-bit word (multiply-shift, no modulo bias worth speaking of) */
+OK_HD uint32_t ok_index_from_word(uint32_t w, uint32_t P)
+{
+    return (uint32_t)(((uint64_t)w * (uint64_t)P) >> 32);
+}
+
+/* start index of agent j in the bench recipe: (j * 2654435761) mod 2^32 mod P */
+OK_HD uint32_t ok_start_index(uint32_t agent, uint32_t P)
+{
+    return (uint32_t)(agent * 2654435761u) % P;
+}
+
+#endif /* OKENV_MATH_H */

@@ -1,0 +1,611 @@
+/*
+ * okenv_oracle.c -- CPU restatement of OpenKitchen's Environment step path.  TEST INFRASTRUCTURE.
+ *
+ * This file is the parity oracle and the CPU baseline ("port") of the project.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; nothing under
+ * openkitchen_amd/ links, imports or calls it, and the product path has no CPU fallback.
+ *
+ * It restates, in plain C and in the reference's fp32 operation order, compiled with
+ * `-O2 -ffp-contract=off` (oracle/Makefile):
+ *   RaceTrack construction ........ Environment/RaceTrack.cpp:3-14,87-114,127-164,166-196,198-229,257-307
+ *   nearest centre-line index ..... Environment/RaceTrack.cpp:16-31
+ *   TrackSegments flattening ...... Environment/TrackSegments.cu:6-42,53-67
+ *   Agent kinematics .............. Environment/Agent.cpp:21-47,82-98,108-119,123-135
+ *   standstill FSM ................ Environment/Environment.h:17-27, Environment/Environment.cpp:16-39
+ *   Environment::step order ....... Environment/Environment.cpp:125-149
+ *   ray build / raycast / epilogue  Environment/CollisionChecker.cu:8-35,37-71,113-174
+ *
+ * Pinning: the reference has no tests or golden vectors for this path.  The
+ * restatement is pinned against the reference's own compilable translation units
+ * (Environment/Agent.cpp, Environment/RaceTrack.cpp built into oracle/_ref/ by oracle/Makefile) in
+ * tests/test_oracle_vs_ref.py, and through committed fixtures generated from them
+ * (tests/golden/, generator tests/golden/make_golden.py).  The raycast itself exists in the reference
+ * only as a CUDA kernel that cannot be built or run here; for it the oracle is a line-by-line
+ * restatement and the pin is structural (known-answer geometric cases in tests/test_oracle_raycast.py).
+ *
+ * Trigonometry: `trig_mode` 0 uses ok_sincosf (include/okenv_math.h), the function the HIP kernels
+ * use -- this is the parity definition.  `trig_mode` 1 uses glibc sinf/cosf, which is what the
+ * reference's host code calls; it is used to validate kinematics bit-for-bit against the reference
+ * objects and to bound the distance between the two definitions.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#include "../include/okenv_math.h"
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+static int g_trig_mode = 0;
+
+ORACLE_API void oracle_set_trig_mode(int mode) { g_trig_mode = mode; }
+ORACLE_API int oracle_get_trig_mode(void) { return g_trig_mode; }
+
+static inline void trig(float x, float *s, float *c)
+{
+    if (g_trig_mode == 1) {
+        *s = sinf(x);
+        *c = cosf(x);
+    } else {
+        ok_sincosf(x, s, c);
+    }
+}
+
+ORACLE_API void oracle_sincosf(const float *x, float *s, float *c, int n)
+{
+    for (int i = 0; i < n; ++i) ok_sincosf(x[i], &s[i], &c[i]);
+}
+
+ORACLE_API void oracle_philox(uint32_t seed, uint32_t agent, uint32_t step, float *thr, float *steer, uint32_t *word)
+{
+    ok_random_action a = ok_draw_random_action(seed, agent, step);
+    *thr = a.throttle;
+    *steer = a.steer;
+    *word = a.reset_word;
+}
+
+/* ============================================================================================ */
+/* RaceTrack                                                                                     */
+/* ============================================================================================ */
+
+typedef struct oracle_track {
+    int P;
+    float *x, *y, *wr, *wl;      /* centre line and (scaled) half widths, RaceTrack::TrackData */
+    float *heading;              /* degrees */
+    float *li, *lo, *ri, *ro;    /* boundaries, xy interleaved, P points each */
+} oracle_track;
+
+ORACLE_API void oracle_track_free(oracle_track *t)
+{
+    if (!t) return;
+    free(t->x); free(t->y); free(t->wr); free(t->wl); free(t->heading);
+    free(t->li); free(t->lo); free(t->ri); free(t->ro);
+    free(t);
+}
+
+/* Environment/RaceTrack.cpp:87-114 */
+static void gradient(const float *in, float *out, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        if (i == 0) out[i] = in[i + 1] - in[i];
+        else if (i == n - 1) out[i] = in[i] - in[i - 1];
+        else out[i] = (in[i + 1] - in[i - 1]) / 2.0f;
+    }
+}
+
+/* Environment/RaceTrack.cpp:166-196 */
+static void extents(const float *x, const float *y, int n, float *minx, float *miny, float *maxx, float *maxy)
+{
+    *minx = FLT_MAX; *miny = FLT_MAX; *maxx = -FLT_MAX; *maxy = -FLT_MAX;
+    for (int i = 0; i < n; ++i) {
+        if (x[i] < *minx) *minx = x[i];
+        if (x[i] > *maxx) *maxx = x[i];
+    }
+    for (int i = 0; i < n; ++i) {
+        if (y[i] < *miny) *miny = y[i];
+        if (y[i] > *maxy) *maxy = y[i];
+    }
+}
+
+static float clamp_width(float w)
+{
+    /* Environment/RaceTrack.cpp:138-160: min(max(4, w) * 3, 17) */
+    float m = (4.0f < w) ? w : 4.0f; /* std::max(4.0f, w) returns w only if 4 < w */
+    float s = m * 3.0f;
+    return (17.0f < s) ? 17.0f : s; /* std::min(s, 17): returns 17 only if 17 < s */
+}
+
+/* Environment/RaceTrack.cpp:127-164 */
+static int parse_csv(const char *path, oracle_track *t)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int cap = 2048, n = 0;
+    t->x = malloc(sizeof(float) * cap); t->y = malloc(sizeof(float) * cap);
+    t->wr = malloc(sizeof(float) * cap); t->wl = malloc(sizeof(float) * cap);
+    char line[1024];
+    if (!fgets(line, sizeof line, f)) { fclose(f); return -2; } /* header */
+    while (fgets(line, sizeof line, f)) {
+        char *p = line;
+        if (*p == '\n' || *p == '\0' || *p == '\r') continue;
+        float v[4];
+        for (int k = 0; k < 4; ++k) {
+            char *end;
+            v[k] = strtof(p, &end); /* std::stof == strtof */
+            p = strchr(p, ',');
+            if (p) ++p; else if (k < 3) { fclose(f); return -3; }
+        }
+        if (n == cap) {
+            cap *= 2;
+            t->x = realloc(t->x, sizeof(float) * cap); t->y = realloc(t->y, sizeof(float) * cap);
+            t->wr = realloc(t->wr, sizeof(float) * cap); t->wl = realloc(t->wl, sizeof(float) * cap);
+        }
+        t->x[n] = v[0]; t->y[n] = v[1];
+        t->wr[n] = clamp_width(v[2]);
+        t->wl[n] = clamp_width(v[3]);
+        ++n;
+    }
+    fclose(f);
+    t->P = n;
+    return 0;
+}
+
+ORACLE_API oracle_track *oracle_track_load(const char *csv_path)
+{
+    oracle_track *t = calloc(1, sizeof *t);
+    if (parse_csv(csv_path, t) != 0 || t->P < 2) { oracle_track_free(t); return NULL; }
+    const int P = t->P;
+    /* Environment/RaceTrack.cpp:198-229 centerTrackPointsToWindow(extent, 1600, 1400) */
+    float minx, miny, maxx, maxy;
+    extents(t->x, t->y, P, &minx, &miny, &maxx, &maxy);
+    const float window_w = 1600.0f, window_h = 1400.0f; /* Environment/Typedefs.h:7-8 */
+    const float track_w = maxx - minx;
+    const float track_h = maxy - miny;
+    float sfx = window_w / track_w;
+    float sfy = window_h / track_h;
+    float sf = (sfy < sfx) ? sfy : sfx; /* std::min(sfx, sfy) */
+    const float kScreenFitScale = 0.9f; /* constexpr float{0.9} */
+    sf *= kScreenFitScale;
+    for (int i = 0; i < P; ++i) {
+        t->x[i] *= sf; t->y[i] *= sf; t->wl[i] *= sf; t->wr[i] *= sf;
+    }
+    extents(t->x, t->y, P, &minx, &miny, &maxx, &maxy);
+    const float dcx = (window_w / 2.0f) - ((maxx + minx) / 2.0f);
+    const float dcy = (window_h / 2.0f) - ((maxy + miny) / 2.0f);
+    for (int i = 0; i < P; ++i) { t->x[i] += dcx; t->y[i] += dcy; }
+
+    /* Environment/RaceTrack.cpp:257-307 calculateTrackLanes */
+    float *dx = malloc(sizeof(float) * P), *dy = malloc(sizeof(float) * P);
+    gradient(t->x, dx, P);
+    gradient(t->y, dy, P);
+    t->heading = malloc(sizeof(float) * P);
+    for (int i = 0; i < P; ++i) {
+        const float mag = sqrtf(dx[i] * dx[i] + dy[i] * dy[i]);
+        dx[i] /= mag;
+        dy[i] /= mag;
+        /* :278  std::atan2(float,float) * 180.0F / M_PI : float*float, then a DOUBLE divide, stored to float */
+        const float a = atan2f(dy[i], dx[i]) * 180.0f;
+        t->heading[i] = (float)((double)a / M_PI);
+    }
+    t->li = malloc(sizeof(float) * 2 * P); t->lo = malloc(sizeof(float) * 2 * P);
+    t->ri = malloc(sizeof(float) * 2 * P); t->ro = malloc(sizeof(float) * 2 * P);
+    const float kBoundaryThickness = 3.0f;
+    for (int i = 0; i < P; ++i) {
+        t->ri[2 * i] = t->x[i] + t->wr[i] * dy[i];
+        t->ri[2 * i + 1] = t->y[i] - t->wr[i] * dx[i];
+        t->li[2 * i] = t->x[i] - t->wl[i] * dy[i];
+        t->li[2 * i + 1] = t->y[i] + t->wl[i] * dx[i];
+        t->ro[2 * i] = t->x[i] + (t->wr[i] + kBoundaryThickness) * dy[i];
+        t->ro[2 * i + 1] = t->y[i] - (t->wr[i] + kBoundaryThickness) * dx[i];
+        t->lo[2 * i] = t->x[i] - (t->wl[i] + kBoundaryThickness) * dy[i];
+        t->lo[2 * i + 1] = t->y[i] + (t->wl[i] + kBoundaryThickness) * dx[i];
+    }
+    free(dx); free(dy);
+    return t;
+}
+
+ORACLE_API int oracle_track_num_points(const oracle_track *t) { return t->P; }
+
+/* which: 0 x, 1 y, 2 w_right, 3 w_left, 4 heading (P floats); 5 li, 6 lo, 7 ri, 8 ro (2P floats) */
+ORACLE_API int oracle_track_get(const oracle_track *t, int which, float *out)
+{
+    const float *src[9] = {t->x, t->y, t->wr, t->wl, t->heading, t->li, t->lo, t->ri, t->ro};
+    if (which < 0 || which > 8) return -1;
+    const size_t n = (which < 5) ? (size_t)t->P : (size_t)2 * t->P;
+    memcpy(out, src[which], n * sizeof(float));
+    return 0;
+}
+
+/* Environment/TrackSegments.cu:6-42,53-67 -- order LI, LO, RI, RO runs then closers LI, RI, LO, RO.
+ * out holds 4*P segments as x1,y1,x2,y2.  Returns the segment count. */
+ORACLE_API int oracle_track_segments(const oracle_track *t, float *out)
+{
+    const int P = t->P;
+    int s = 0;
+    const float *poly[4] = {t->li, t->lo, t->ri, t->ro};
+    for (int q = 0; q < 4; ++q) {
+        for (int i = 0; i + 1 < P; ++i) {
+            out[4 * s + 0] = poly[q][2 * i]; out[4 * s + 1] = poly[q][2 * i + 1];
+            out[4 * s + 2] = poly[q][2 * i + 2]; out[4 * s + 3] = poly[q][2 * i + 3];
+            ++s;
+        }
+    }
+    if (P > 1) {
+        const float *closers[4] = {t->li, t->ri, t->lo, t->ro};
+        for (int q = 0; q < 4; ++q) {
+            out[4 * s + 0] = closers[q][2 * (P - 1)]; out[4 * s + 1] = closers[q][2 * (P - 1) + 1];
+            out[4 * s + 2] = closers[q][0]; out[4 * s + 3] = closers[q][1];
+            ++s;
+        }
+    }
+    return s;
+}
+
+/* Environment/RaceTrack.cpp:16-31; Vec2d::distanceSquared Environment/Typedefs.h:41-44 */
+ORACLE_API void oracle_nearest_track_idx(const float *cx, const float *cy, int P, const float *qx, const float *qy,
+                                         int n, int32_t *out)
+{
+    for (int j = 0; j < n; ++j) {
+        float best = FLT_MAX;
+        int bi = 0;
+        for (int i = 0; i < P; ++i) {
+            const float ddx = qx[j] - cx[i], ddy = qy[j] - cy[i];
+            const float d = ddx * ddx + ddy * ddy;
+            if (d < best) { best = d; bi = i; }
+        }
+        out[j] = bi;
+    }
+}
+
+/* ============================================================================================ */
+/* Environment state (SoA mirror of N Agent objects + DisplacementStats + Ray_ hit points)       */
+/* ============================================================================================ */
+
+typedef struct oracle_env {
+    int N, R, S;
+    float *segs;        /* S * 4 */
+    float *ray_deg;     /* R, Agent::sensor_ray_angles_ */
+    float sensor_offset;
+    /* Agent fields */
+    float *pos_x, *pos_y, *rot, *speed, *acc, *thr, *steer;
+    uint8_t *mode, *crashed, *timed_out;
+    /* DisplacementStats */
+    uint32_t *disp_ctr;
+    float *disp_x, *disp_y;
+    uint8_t *disp_to;
+    /* Ray_ persistent fields (world-frame hit point), N*R each; zero before the first step
+     * (the reference's pinned buffer is uninitialised -- defined as zeros) */
+    float *hit_x, *hit_y;
+    /* outputs of the epilogue: sensor_hits_ (robot frame) and their norms */
+    float *rel_x, *rel_y, *dist;
+    /* centre line for resets / nearest index */
+    int P;
+    float *cx, *cy, *chead;
+} oracle_env;
+
+#define ALLOC(T, n) ((T *)calloc((size_t)(n), sizeof(T)))
+
+ORACLE_API oracle_env *oracle_env_create(const float *segs, int S, int N, int R, const float *ray_deg)
+{
+    oracle_env *e = ALLOC(oracle_env, 1);
+    e->N = N; e->R = R; e->S = S;
+    e->segs = ALLOC(float, 4 * (size_t)S); memcpy(e->segs, segs, sizeof(float) * 4 * (size_t)S);
+    e->ray_deg = ALLOC(float, R); memcpy(e->ray_deg, ray_deg, sizeof(float) * R);
+    e->sensor_offset = 0.0f; /* Environment/Agent.h:61 */
+    e->pos_x = ALLOC(float, N); e->pos_y = ALLOC(float, N); e->rot = ALLOC(float, N);
+    e->speed = ALLOC(float, N); e->acc = ALLOC(float, N); e->thr = ALLOC(float, N); e->steer = ALLOC(float, N);
+    e->mode = ALLOC(uint8_t, N); e->crashed = ALLOC(uint8_t, N); e->timed_out = ALLOC(uint8_t, N);
+    e->disp_ctr = ALLOC(uint32_t, N); e->disp_x = ALLOC(float, N); e->disp_y = ALLOC(float, N);
+    e->disp_to = ALLOC(uint8_t, N);
+    const size_t NR = (size_t)N * R;
+    e->hit_x = ALLOC(float, NR); e->hit_y = ALLOC(float, NR);
+    e->rel_x = ALLOC(float, NR); e->rel_y = ALLOC(float, NR); e->dist = ALLOC(float, NR);
+    return e;
+}
+
+ORACLE_API void oracle_env_destroy(oracle_env *e)
+{
+    if (!e) return;
+    free(e->segs); free(e->ray_deg);
+    free(e->pos_x); free(e->pos_y); free(e->rot); free(e->speed); free(e->acc); free(e->thr); free(e->steer);
+    free(e->mode); free(e->crashed); free(e->timed_out);
+    free(e->disp_ctr); free(e->disp_x); free(e->disp_y); free(e->disp_to);
+    free(e->hit_x); free(e->hit_y); free(e->rel_x); free(e->rel_y); free(e->dist);
+    free(e->cx); free(e->cy); free(e->chead);
+    free(e);
+}
+
+ORACLE_API void oracle_env_set_centerline(oracle_env *e, const float *cx, const float *cy, const float *head, int P)
+{
+    free(e->cx); free(e->cy); free(e->chead);
+    e->P = P;
+    e->cx = ALLOC(float, P); e->cy = ALLOC(float, P); e->chead = ALLOC(float, P);
+    memcpy(e->cx, cx, sizeof(float) * P); memcpy(e->cy, cy, sizeof(float) * P); memcpy(e->chead, head, sizeof(float) * P);
+}
+
+ORACLE_API void oracle_env_set_sensor_offset(oracle_env *e, float off) { e->sensor_offset = off; }
+
+/* field ids shared with include/okenv.h (OKENV_F_*) */
+enum { F_POS_X = 0, F_POS_Y, F_ROT, F_SPEED, F_ACC, F_THR, F_STEER, F_MODE, F_CRASHED, F_TIMED_OUT,
+       F_DISP_CTR, F_DISP_X, F_DISP_Y, F_DISP_TO, F_HIT_X, F_HIT_Y, F_REL_X, F_REL_Y, F_DIST, F_COUNT };
+
+static void *field_ptr(oracle_env *e, int f, size_t *bytes)
+{
+    const size_t N = e->N, NR = (size_t)e->N * e->R;
+    switch (f) {
+    case F_POS_X: *bytes = 4 * N; return e->pos_x;
+    case F_POS_Y: *bytes = 4 * N; return e->pos_y;
+    case F_ROT: *bytes = 4 * N; return e->rot;
+    case F_SPEED: *bytes = 4 * N; return e->speed;
+    case F_ACC: *bytes = 4 * N; return e->acc;
+    case F_THR: *bytes = 4 * N; return e->thr;
+    case F_STEER: *bytes = 4 * N; return e->steer;
+    case F_MODE: *bytes = N; return e->mode;
+    case F_CRASHED: *bytes = N; return e->crashed;
+    case F_TIMED_OUT: *bytes = N; return e->timed_out;
+    case F_DISP_CTR: *bytes = 4 * N; return e->disp_ctr;
+    case F_DISP_X: *bytes = 4 * N; return e->disp_x;
+    case F_DISP_Y: *bytes = 4 * N; return e->disp_y;
+    case F_DISP_TO: *bytes = N; return e->disp_to;
+    case F_HIT_X: *bytes = 4 * NR; return e->hit_x;
+    case F_HIT_Y: *bytes = 4 * NR; return e->hit_y;
+    case F_REL_X: *bytes = 4 * NR; return e->rel_x;
+    case F_REL_Y: *bytes = 4 * NR; return e->rel_y;
+    case F_DIST: *bytes = 4 * NR; return e->dist;
+    default: *bytes = 0; return NULL;
+    }
+}
+
+ORACLE_API int oracle_env_set_field(oracle_env *e, int f, const void *src)
+{
+    size_t b; void *p = field_ptr(e, f, &b);
+    if (!p) return -1;
+    memcpy(p, src, b);
+    return 0;
+}
+
+ORACLE_API int oracle_env_get_field(oracle_env *e, int f, void *dst)
+{
+    size_t b; void *p = field_ptr(e, f, &b);
+    if (!p) return -1;
+    memcpy(dst, p, b);
+    return 0;
+}
+
+/* Environment/Agent.cpp:123-135 Agent::reset -- note: DisplacementStats are NOT touched (appendix A.5) */
+static void agent_reset(oracle_env *e, int i, float x, float y, float rot)
+{
+    e->pos_x[i] = x; e->pos_y[i] = y; e->rot[i] = rot;
+    e->acc[i] = 0.0f; e->speed[i] = 0.0f;
+    e->crashed[i] = 0; e->timed_out[i] = 0;
+    e->thr[i] = 0.0f; e->steer[i] = 0.0f;
+}
+
+ORACLE_API void oracle_env_reset_agents(oracle_env *e, const int32_t *idx, const float *x, const float *y,
+                                        const float *rot, int n)
+{
+    for (int k = 0; k < n; ++k) agent_reset(e, idx[k], x[k], y[k], rot[k]);
+}
+
+/* Environment/Agent.cpp:21-47 dispatch, :108-119 moveViaVelocity, :82-98 moveViaAcceleration.
+ * `cos(kDeg2Rad * rot_) * speed_ * kDt` is ((cos * speed) * dt), all fp32. */
+static void agent_move(oracle_env *e, int i)
+{
+    if (e->mode[i] == 0) {
+        e->rot[i] += e->steer[i];
+        e->speed[i] = e->thr[i];
+    } else if (e->mode[i] == 1) {
+        e->rot[i] += e->steer[i];
+        e->acc[i] += e->thr[i];
+        e->speed[i] += (e->acc[i] * OK_DT);
+        e->speed[i] = (e->speed[i] < 0.0f) ? 0.0f : e->speed[i];
+        e->speed[i] = (e->speed[i] > OK_SPEED_LIMIT) ? OK_SPEED_LIMIT : e->speed[i];
+    } else {
+        return; /* MANUAL is an empty stub, Environment/Agent.cpp:50-79 */
+    }
+    float s, c;
+    trig(OK_DEG2RAD * e->rot[i], &s, &c);
+    const float dx = c * e->speed[i] * OK_DT;
+    e->pos_x[i] += dx;
+    const float dy = s * e->speed[i] * OK_DT;
+    e->pos_y[i] += dy;
+}
+
+/* Environment/Environment.cpp:16-39 */
+static void standstill(oracle_env *e, int i)
+{
+    if (e->disp_ctr[i] == 0) {
+        e->disp_x[i] = e->pos_x[i]; e->disp_y[i] = e->pos_y[i];
+        e->disp_to[i] = 0;
+        e->disp_ctr[i]++;
+        return;
+    }
+    if (e->disp_ctr[i] >= OK_DISP_PERIOD) {
+        const float ddx = e->pos_x[i] - e->disp_x[i], ddy = e->pos_y[i] - e->disp_y[i];
+        const float d2 = ddx * ddx + ddy * ddy; /* Vec2d::distanceSquared */
+        if (d2 < OK_DISP_THRESH2) e->disp_to[i] = 1;
+        e->disp_ctr[i] = 0;
+    } else {
+        e->disp_to[i] = 0;
+        e->disp_ctr[i]++;
+    }
+}
+
+/* Environment/CollisionChecker.cu:8-35 */
+static int ray_segment(float ox, float oy, float rdx, float rdy, float x1, float y1, float x2, float y2,
+                       float range, float *out_t)
+{
+    const float sdx = x2 - x1;
+    const float sdy = y2 - y1;
+    const float denom = rdx * sdy - rdy * sdx;
+    if (fabsf(denom) < OK_PARALLEL_EPS) return 0;
+    const float t = ((x1 - ox) * sdy - (y1 - oy) * sdx) / denom;
+    const float s = ((x1 - ox) * rdy - (y1 - oy) * rdx) / denom;
+    if ((t >= 0.0f) && (t <= range) && (s >= 0.0f) && (s <= 1.0f)) { *out_t = t; return 1; }
+    return 0;
+}
+
+/* Environment/CollisionChecker.cu:113-174 for agents [a0,a1): prologue (ray build), kernel, epilogue.
+ * tests_out (optional) accumulates the ray-segment test count. */
+static void collide_range(oracle_env *e, int a0, int a1)
+{
+    const int R = e->R, S = e->S;
+    for (int i = a0; i < a1; ++i) {
+        float sr, cr;
+        trig(OK_DEG2RAD * e->rot[i], &sr, &cr);
+        /* :121-124 origin = pos + sensor_offset * (cos, sin) */
+        const float ox = e->pos_x[i] + e->sensor_offset * cr;
+        const float oy = e->pos_y[i] + e->sensor_offset * sr;
+        const int active = !e->crashed[i];
+        float min_d2 = OK_SENSOR_RANGE * OK_SENSOR_RANGE;
+        for (int r = 0; r < R; ++r) {
+            const size_t k = (size_t)i * R + r;
+            if (active) {
+                /* :125 angle, :47-48 direction, :49-67 shrinking-range sweep, :69-70 hit point */
+                const float angle = OK_DEG2RAD * (e->rot[i] + e->ray_deg[r]);
+                float rdy, rdx;
+                trig(angle, &rdy, &rdx);
+                float min_t = OK_SENSOR_RANGE;
+                const float *sg = e->segs;
+                for (int j = 0; j < S; ++j, sg += 4) {
+                    float t;
+                    if (ray_segment(ox, oy, rdx, rdy, sg[0], sg[1], sg[2], sg[3], min_t, &t)) min_t = t;
+                }
+                e->hit_x[k] = ox + min_t * rdx;
+                e->hit_y[k] = oy + min_t * rdy;
+            }
+            /* :144-166 epilogue runs for every ray, stale hit points included (appendix A.8) */
+            const float xt = e->hit_x[k] - ox;
+            const float yt = e->hit_y[k] - oy;
+            const float hx = xt * cr - yt * sr;
+            const float hy = xt * sr + yt * cr;
+            e->rel_x[k] = hx; e->rel_y[k] = hy;
+            const float n2 = hx * hx + hy * hy;
+            e->dist[k] = sqrtf(n2); /* Vec2d::norm(), what every in-scope policy consumes */
+            if (n2 < min_d2) min_d2 = n2;
+        }
+        if (min_d2 < OK_CRASH_DIST2) e->crashed[i] = 1;
+    }
+}
+
+ORACLE_API void oracle_env_collide(oracle_env *e) { collide_range(e, 0, e->N); }
+
+/* Environment/Environment.cpp:125-149 minus render(), for agents [a0,a1) */
+static void step_range(oracle_env *e, int a0, int a1)
+{
+    for (int i = a0; i < a1; ++i) {
+        if (!e->crashed[i]) {
+            agent_move(e, i);
+            standstill(e, i);
+            if (e->disp_to[i]) { e->crashed[i] = 1; e->timed_out[i] = 1; }
+        }
+    }
+    collide_range(e, a0, a1);
+}
+
+ORACLE_API void oracle_env_step(oracle_env *e, int n_steps)
+{
+    for (int s = 0; s < n_steps; ++s) step_range(e, 0, e->N);
+}
+
+/* kinematics + standstill only (validated against the reference's Agent.o) */
+ORACLE_API void oracle_env_move_only(oracle_env *e)
+{
+    for (int i = 0; i < e->N; ++i) {
+        if (!e->crashed[i]) {
+            agent_move(e, i);
+            standstill(e, i);
+            if (e->disp_to[i]) { e->crashed[i] = 1; e->timed_out[i] = 1; }
+        }
+    }
+}
+
+/*
+ * The bench driver loop (shape of RLRacers/GuidedCostLearning/test.cpp:100-117):
+ * per step: crashed agents are re-placed on a Philox-chosen centre-line point (Agent::reset), every
+ * agent draws a fresh action, then Environment::step.  `agent_base` is the global id of agent 0 (for
+ * sharded populations), `step_base` the global index of the first step.
+ */
+static void rollout_range(oracle_env *e, int a0, int a1, int n_steps, uint32_t seed, uint32_t agent_base,
+                          uint32_t step_base)
+{
+    for (int s = 0; s < n_steps; ++s) {
+        for (int i = a0; i < a1; ++i) {
+            const ok_random_action a = ok_draw_random_action(seed, agent_base + (uint32_t)i, step_base + (uint32_t)s);
+            if (e->crashed[i]) {
+                const uint32_t idx = ok_index_from_word(a.reset_word, (uint32_t)e->P);
+                agent_reset(e, i, e->cx[idx], e->cy[idx], e->chead[idx]);
+            }
+            e->thr[i] = a.throttle;
+            e->steer[i] = a.steer;
+        }
+        step_range(e, a0, a1);
+    }
+}
+
+ORACLE_API void oracle_env_rollout_random(oracle_env *e, int n_steps, uint32_t seed, uint32_t agent_base,
+                                          uint32_t step_base)
+{
+    rollout_range(e, 0, e->N, n_steps, seed, agent_base, step_base);
+}
+
+/* bench recipe initial state: agent j on centre-line index ok_start_index(j), track heading, mode */
+ORACLE_API void oracle_env_init_bench_state(oracle_env *e, uint32_t agent_base, int mode)
+{
+    for (int i = 0; i < e->N; ++i) {
+        const uint32_t idx = ok_start_index(agent_base + (uint32_t)i, (uint32_t)e->P);
+        agent_reset(e, i, e->cx[idx], e->cy[idx], e->chead[idx]);
+        e->mode[i] = (uint8_t)mode;
+        e->disp_ctr[i] = 0; e->disp_x[i] = 0.0f; e->disp_y[i] = 0.0f; e->disp_to[i] = 0;
+    }
+    memset(e->hit_x, 0, sizeof(float) * (size_t)e->N * e->R);
+    memset(e->hit_y, 0, sizeof(float) * (size_t)e->N * e->R);
+}
+
+/*
+ * Multi-threaded variant for the separately-labelled "all host cores" CPU row:
+ * agents are partitioned into contiguous blocks, no shared writes.  Plain pthreads.
+ */
+#include <pthread.h>
+typedef struct { oracle_env *e; int a0, a1, n_steps; uint32_t seed, agent_base, step_base; } mt_job;
+static void *mt_main(void *p)
+{
+    mt_job *j = (mt_job *)p;
+    rollout_range(j->e, j->a0, j->a1, j->n_steps, j->seed, j->agent_base, j->step_base);
+    return NULL;
+}
+
+ORACLE_API void oracle_env_rollout_random_mt(oracle_env *e, int n_steps, uint32_t seed, uint32_t agent_base,
+                                             uint32_t step_base, int threads)
+{
+    if (threads < 1) threads = 1;
+    if (threads > e->N) threads = e->N;
+    pthread_t *th = malloc(sizeof(pthread_t) * threads);
+    mt_job *jobs = malloc(sizeof(mt_job) * threads);
+    for (int t = 0; t < threads; ++t) {
+        jobs[t].e = e;
+        jobs[t].a0 = (int)((long long)e->N * t / threads);
+        jobs[t].a1 = (int)((long long)e->N * (t + 1) / threads);
+        jobs[t].n_steps = n_steps; jobs[t].seed = seed; jobs[t].agent_base = agent_base; jobs[t].step_base = step_base;
+        pthread_create(&th[t], NULL, mt_main, &jobs[t]);
+    }
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    free(th); free(jobs);
+}
+
+/* stand-alone raycast for known-answer tests: one ray against S segments, returns min_t */
+ORACLE_API float oracle_cast_ray(float ox, float oy, float angle_rad, const float *segs, int S)
+{
+    float rdy, rdx;
+    trig(angle_rad, &rdy, &rdx);
+    float min_t = OK_SENSOR_RANGE;
+    for (int j = 0; j < S; ++j) {
+        float t;
+        if (ray_segment(ox, oy, rdx, rdy, segs[4 * j], segs[4 * j + 1], segs[4 * j + 2], segs[4 * j + 3], min_t, &t))
+            min_t = t;
+    }
+    return min_t;
+}
