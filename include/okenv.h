@@ -1,0 +1,201 @@
+/*
+ * okenv.h -- C ABI of the MI355X-native batched Environment step (libokenv.so).
+ *
+ * This is the drop-in boundary for the hot path of goksanisil23/OpenKitchen (paths below are relative to
+ * the reference tree): everything `Environment::step()` does per step -- Agent kinematics, the
+ * standstill timeout, the 2-D raycast lidar against the RaceTrack's boundary segments and the
+ * lidar-based crash test -- for N agents x R rays per launch, with the agent state resident on the GPU
+ * as struct-of-arrays.  The C++ classes in include/Environment/ (same names and members as the
+ * reference's) are thin hosts over these entry points; INTEGRATION.md shows the binding a maintainer of
+ * the reference would add.
+ *
+ * Conventions: every function returns an int status (OKENV_OK == 0, negative on error) unless noted; no
+ * exception crosses this boundary; `okenv_last_error` returns a message for the most recent failure on
+ * the handle (or globally, for NULL).  Host buffers are caller-owned; device buffers are library-owned.
+ * A handle owns one HIP stream; work is enqueued asynchronously and the `get`/`download` calls
+ * synchronise.  A handle is used by one thread at a time; multi-GPU means one handle per device (one
+ * process per GPU in bench.py).  Pointers passed to `okenv_set_field` / `okenv_get_field` /
+ * `okenv_set_actions` may be host OR device pointers (hipMemcpyDefault).
+ */
+#ifndef OKENV_H
+#define OKENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#define OKENV_API
+#else
+#define OKENV_API __attribute__((visibility("default")))
+#endif
+
+#define OKENV_OK 0
+#define OKENV_ERR_INVALID (-1)  /* bad argument */
+#define OKENV_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define OKENV_ERR_NO_DEVICE (-3)/* no usable GPU: the product path has NO CPU fallback */
+#define OKENV_ERR_IO (-4)       /* track CSV could not be read */
+#define OKENV_ERR_STATE (-5)    /* call not valid in the handle's current state */
+
+typedef struct okenv *okenv_t;
+typedef struct okenv_track *okenv_track_t;
+
+/* Agent::MovementMode, Environment/Agent.h:20-25 */
+#define OKENV_MODE_VELOCITY 0
+#define OKENV_MODE_ACCELERATION 1
+#define OKENV_MODE_MANUAL 2
+
+/* okenv_create flags */
+#define OKENV_FLAG_NONE 0u
+#define OKENV_FLAG_FORCE_GLOBAL_GRID 1u /* keep the grid in global memory even if it fits LDS (testing) */
+#define OKENV_FLAG_BRUTE_FORCE 2u       /* sweep all segments like the reference kernel (testing / ablation) */
+
+/*
+ * State fields (struct-of-arrays).  One value per agent unless marked [N*R] (agent-major, ray-minor).
+ * They mirror, field for field, what the reference keeps per Agent (Environment/Agent.h:56-81), per
+ * DisplacementStats (Environment/Environment.h:17-27) and per Ray_ (Environment/Typedefs.h:91-99).
+ */
+enum okenv_field {
+    OKENV_F_POS_X = 0,     /* f32  Agent::pos_.x                                    */
+    OKENV_F_POS_Y = 1,     /* f32  Agent::pos_.y                                    */
+    OKENV_F_ROT = 2,       /* f32  Agent::rot_ [deg], never wrapped                 */
+    OKENV_F_SPEED = 3,     /* f32  Agent::speed_                                    */
+    OKENV_F_ACC = 4,       /* f32  Agent::acceleration_                             */
+    OKENV_F_THROTTLE = 5,  /* f32  Agent::current_action_.throttle_delta            */
+    OKENV_F_STEER = 6,     /* f32  Agent::current_action_.steering_delta            */
+    OKENV_F_MODE = 7,      /* u8   Agent::movement_mode_                            */
+    OKENV_F_CRASHED = 8,   /* u8   Agent::crashed_                                  */
+    OKENV_F_TIMED_OUT = 9, /* u8   Agent::timed_out_                                */
+    OKENV_F_DISP_CTR = 10, /* u32  DisplacementStats::displacement_ctr              */
+    OKENV_F_DISP_X = 11,   /* f32  DisplacementStats::init_pos.x                    */
+    OKENV_F_DISP_Y = 12,   /* f32  DisplacementStats::init_pos.y                    */
+    OKENV_F_DISP_TO = 13,  /* u8   DisplacementStats::displacement_timed_out        */
+    OKENV_F_HIT_X = 14,    /* f32 [N*R] Ray_::hit_x (world frame, persists while crashed) */
+    OKENV_F_HIT_Y = 15,    /* f32 [N*R] Ray_::hit_y                                 */
+    OKENV_F_REL_X = 16,    /* f32 [N*R] Agent::sensor_hits_[r].x ("robot frame")    */
+    OKENV_F_REL_Y = 17,    /* f32 [N*R] Agent::sensor_hits_[r].y                    */
+    OKENV_F_DIST = 18,     /* f32 [N*R] Agent::sensor_hits_[r].norm()               */
+    OKENV_F_COUNT = 19
+};
+
+/* Struct-of-pointers form of the per-agent state, for one-call upload/download by the C++ facade.
+ * NULL members are skipped. */
+typedef struct okenv_state_view {
+    float *pos_x, *pos_y, *rot, *speed, *acc, *throttle, *steer;
+    uint8_t *mode, *crashed, *timed_out;
+    uint32_t *disp_ctr;
+    float *disp_x, *disp_y;
+    uint8_t *disp_timed_out;
+} okenv_state_view;
+
+typedef struct okenv_info {
+    int32_t num_agents, num_rays, num_segments;
+    int32_t grid_nx, grid_ny;
+    float grid_cell;
+    int32_t grid_refs;        /* total segment registrations */
+    int32_t grid_in_lds;      /* 1: grid + segments staged in LDS per workgroup, 0: read from global memory */
+    int32_t lds_bytes;        /* dynamic LDS per workgroup */
+    int32_t block_threads;    /* workgroup size of the step kernel */
+    int32_t grid_blocks;      /* workgroups per launch */
+    int32_t lanes_per_agent;  /* G: power of two >= R, capped at 64 */
+    int32_t device;
+} okenv_info;
+
+/* ---- lifetime ------------------------------------------------------------------------------------ */
+
+/*
+ * Replaces: TrackSegments::uploadToDevice (Environment/TrackSegments.cu:69-76) + CollisionChecker::Impl
+ * constructor (Environment/CollisionChecker.cu:76-86) + Environment's displacement_stats_.resize
+ * (Environment/Environment.cpp:61).  `segments_xyxy` is the reference's Segment2d[S] layout
+ * (x1,y1,x2,y2); `ray_angles_deg` is Agent::sensor_ray_angles_ (all agents share one fan,
+ * CollisionChecker.cu:82).  All state starts zeroed (mode VELOCITY, not crashed).
+ * `grid_cell` <= 0 selects the default cell edge.
+ */
+OKENV_API int okenv_create(okenv_t *out, const float *segments_xyxy, int32_t num_segments, int32_t num_agents,
+                           int32_t num_rays, const float *ray_angles_deg, int32_t device, uint32_t flags,
+                           float grid_cell);
+/* Replaces ~CollisionChecker / ~TrackSegments (Environment/CollisionChecker.cu:88-94, TrackSegments.cu:44-51). */
+OKENV_API int okenv_destroy(okenv_t h);
+OKENV_API int okenv_get_info(okenv_t h, okenv_info *out);
+/* Message for the last failure on `h` (or the last create failure if h is NULL).  Never NULL. */
+OKENV_API const char *okenv_last_error(okenv_t h);
+/* Agent::sensor_offset_ (Environment/Agent.h:61), shared by all agents; default 0. */
+OKENV_API int okenv_set_sensor_offset(okenv_t h, float offset);
+/* Centre line + headings (RaceTrack::track_data_points_.x_m/y_m, headings_), needed by the nearest-index
+ * query and by the on-device reset in okenv_rollout_random. */
+OKENV_API int okenv_set_centerline(okenv_t h, const float *x, const float *y, const float *heading_deg, int32_t num_points);
+/* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the private one. */
+OKENV_API int okenv_set_stream(okenv_t h, void *hip_stream);
+OKENV_API int okenv_sync(okenv_t h);
+
+/* ---- state access -------------------------------------------------------------------------------- */
+
+OKENV_API int okenv_set_field(okenv_t h, int32_t field, const void *src);
+OKENV_API int okenv_get_field(okenv_t h, int32_t field, void *dst); /* synchronises */
+OKENV_API int okenv_upload_state(okenv_t h, const okenv_state_view *host_view);
+OKENV_API int okenv_download_state(okenv_t h, const okenv_state_view *host_view); /* synchronises */
+/* Agent::current_action_ for every agent (what callers write before Environment::step, Template/main.cpp:107-110). */
+OKENV_API int okenv_set_actions(okenv_t h, const float *throttle, const float *steer);
+/* Agent::reset (Environment/Agent.cpp:123-135) for agents idx[0..n): pose set, speed/acc/action zeroed,
+ * crashed/timed_out cleared; DisplacementStats untouched, as in the reference.  Host arrays. */
+OKENV_API int okenv_reset_agents(okenv_t h, const int32_t *idx, const float *x, const float *y, const float *rot_deg, int32_t n);
+/* Agent::sensor_hits_ as interleaved (x,y) pairs [N*R*2], Agent::sensor_hits_[r].norm() [N*R], and
+ * crashed_/timed_out_ as bit0/bit1 of one byte per agent.  Synchronise. */
+OKENV_API int okenv_get_hits(okenv_t h, float *out_xy);
+OKENV_API int okenv_get_distances(okenv_t h, float *out);
+OKENV_API int okenv_get_flags(okenv_t h, uint8_t *out);
+
+/* ---- the hot path -------------------------------------------------------------------------------- */
+
+/* Environment::step() x n_steps (Environment/Environment.cpp:125-149, minus render): move + standstill for
+ * non-crashed agents, then the collision pass for all.  Uses the actions currently stored. */
+OKENV_API int okenv_step(okenv_t h, int32_t n_steps);
+/* CollisionChecker::checkCollision() alone (Environment/CollisionChecker.cu:197-200): ray build, first-hit
+ * raycast, hit transform, crash flag; no kinematics. */
+OKENV_API int okenv_collide(okenv_t h);
+/* The bench driver loop on the device (shape of RLRacers/GuidedCostLearning/test.cpp:100-117; recipe in
+ * SURVEY.md section 8d): per step, crashed agents are re-placed on a Philox-chosen centre-line point, every
+ * agent draws throttle~U[0,100) and steer~U[-5,5) from Philox4x32 keyed (seed; agent_base+i, step_base+s),
+ * then Environment::step.  Requires okenv_set_centerline. */
+OKENV_API int okenv_rollout_random(okenv_t h, int32_t n_steps, uint32_t seed, uint32_t agent_base, uint32_t step_base);
+/* Bench initial state: agent i on centre-line index ((agent_base+i)*2654435761 mod 2^32) mod P with the track
+ * heading, speed 0, DisplacementStats and hit points zeroed, all agents in `mode`. */
+OKENV_API int okenv_init_bench_state(okenv_t h, uint32_t agent_base, int32_t mode);
+/* RaceTrack::findNearestTrackIndexBruteForce (Environment/RaceTrack.cpp:16-31) for n query points
+ * (host or device pointers), or for every agent's current position when qx == NULL (n ignored). */
+OKENV_API int okenv_nearest_track_idx(okenv_t h, const float *qx, const float *qy, int32_t n, int32_t *out);
+
+/* ---- measurement --------------------------------------------------------------------------------- */
+
+/* When enabled, every step/collide/rollout launch is bracketed by HIP events on the handle's stream. */
+OKENV_API int okenv_set_timing(okenv_t h, int32_t enabled);
+/* Sum of the bracketed kernel durations [ms] and their count since the last call; synchronises, then clears. */
+OKENV_API int okenv_get_timing(okenv_t h, double *total_ms, uint64_t *launches);
+
+/* ---- host-side track construction (RaceTrack + TrackSegments, no GPU involved) -------------------- */
+
+/* RaceTrack::RaceTrack(csv) (Environment/RaceTrack.cpp:3-14). */
+OKENV_API int okenv_track_load(okenv_track_t *out, const char *csv_path);
+OKENV_API int okenv_track_free(okenv_track_t t);
+OKENV_API int32_t okenv_track_num_points(okenv_track_t t);
+OKENV_API int32_t okenv_track_num_segments(okenv_track_t t);
+/* which: 0 x_m, 1 y_m, 2 w_tr_right_m, 3 w_tr_left_m, 4 headings_ (P floats);
+ *        5 left_bound_inner_, 6 left_bound_outer_, 7 right_bound_inner_, 8 right_bound_outer_ (2P floats, xy) */
+OKENV_API int okenv_track_get(okenv_track_t t, int32_t which, float *out);
+/* TrackSegments::TrackSegments (Environment/TrackSegments.cu:6-42): 4*P segments, x1,y1,x2,y2 each. */
+OKENV_API int okenv_track_segments(okenv_track_t t, float *out_xyxy);
+
+/* ---- device self-checks used by the parity tests --------------------------------------------------- */
+
+/* ok_sincosf evaluated on the GPU (n values, host pointers). */
+OKENV_API int okenv_debug_sincos(int32_t device, const float *x, float *s, float *c, int32_t n);
+/* First-hit parameter t for n arbitrary rays (origin, angle [rad]) through the handle's grid (host pointers). */
+OKENV_API int okenv_debug_cast_rays(okenv_t h, const float *ox, const float *oy, const float *angle_rad, int32_t n, float *out_t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OKENV_H */

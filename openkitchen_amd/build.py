@@ -1,0 +1,64 @@
+"""Builds libokenv.so (HIP kernels + C ABI + C++ Environment facade) in-tree for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only development container as well as on the
+MI355X box.  The shared object is git-ignored but travels with the gpurun snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libokenv.so")
+
+HIP_SOURCES = [os.path.join(CSRC, "okenv_capi.hip")]
+CXX_SOURCES = [
+    os.path.join(CSRC, "facade", "RaceTrack.cpp"),
+    os.path.join(CSRC, "facade", "Agent.cpp"),
+    os.path.join(CSRC, "facade", "Environment.cpp"),
+]
+HEADERS = [
+    os.path.join(CSRC, "ok_raycast.h"), os.path.join(CSRC, "ok_grid.h"), os.path.join(CSRC, "okenv_kernels.h"),
+    os.path.join(ROOT, "include", "okenv.h"), os.path.join(ROOT, "include", "okenv_math.h"),
+]
+
+# -ffp-contract=off: crash/done flags must be bit-exact against the CPU oracle, and FMA contraction changes
+# the cancellation-prone 2x2 determinants of the ray-segment test ("FMA contraction").
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "--offload-arch=gfx950",
+         "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+
+
+def sources():
+    return HIP_SOURCES + [s for s in CXX_SOURCES if os.path.exists(s)]
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = sources() + HEADERS + [os.path.join(ROOT, "include", "Environment", f)
+                                  for f in os.listdir(os.path.join(ROOT, "include", "Environment"))]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [_hipcc()] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB_PATH] + sources()
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, cwd=ROOT)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,224 @@
+// ok_grid.h -- host-side construction of the uniform grid the raycast walks (see ok_raycast.h).
+//
+// New functionality: the reference uploads the flat Segment2d array and every ray tests every segment
+// (/root/reference Environment/TrackSegments.cu:69-76, Environment/CollisionChecker.cu:49-67).  Here the
+// segments are binned once per Environment so that a ray only meets the few segments near its path.
+//
+// Registration rule (what the exactness argument in ok_raycast.h relies on): a segment is registered in
+// every cell whose box, inflated by `margin` on all sides, is touched by the segment.  The grid's own
+// box is the segments' bounding box inflated by 2*margin, so nothing lies outside it.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "ok_raycast.h"
+
+struct OkGridHost
+{
+    OkGridGeom            g{};
+    float                 margin{0.F};
+    std::vector<uint32_t> start; // CSR, ncell + 1
+    std::vector<uint32_t> refs;  // segment indices, cell-major
+    uint32_t              max_count{0};
+
+    size_t numCells() const
+    {
+        return static_cast<size_t>(g.nx) * static_cast<size_t>(g.ny);
+    }
+    // compact (16-bit) form usable?
+    bool fits16(const size_t num_segments) const
+    {
+        return num_segments <= 65535U && refs.size() <= 65535U && max_count <= 65535U;
+    }
+    // bytes of the LDS image: segments (16 B) | hdr (4 B per cell) | refs (2 B each), each part 16-B aligned
+    static size_t align16(const size_t v)
+    {
+        return (v + 15U) & ~static_cast<size_t>(15U);
+    }
+    size_t imageBytes16(const size_t num_segments) const
+    {
+        return align16(num_segments * 16U) + align16(numCells() * 4U) + align16(refs.size() * 2U);
+    }
+};
+
+namespace okgrid
+{
+// Does segment (ax,ay)-(bx,by) touch the axis-aligned box [lx,hx]x[ly,hy]?  Liang-Barsky in fp64.
+inline bool segmentTouchesBox(double ax, double ay, double bx, double by, double lx, double ly, double hx, double hy)
+{
+    double       t0 = 0.0, t1 = 1.0;
+    const double dx = bx - ax, dy = by - ay;
+    const double p[4] = {-dx, dx, -dy, dy};
+    const double q[4] = {ax - lx, hx - ax, ay - ly, hy - ay};
+    for (int i = 0; i < 4; ++i)
+    {
+        if (p[i] == 0.0)
+        {
+            if (q[i] < 0.0)
+                return false;
+        }
+        else
+        {
+            const double r = q[i] / p[i];
+            if (p[i] < 0.0)
+            {
+                if (r > t1)
+                    return false;
+                if (r > t0)
+                    t0 = r;
+            }
+            else
+            {
+                if (r < t0)
+                    return false;
+                if (r < t1)
+                    t1 = r;
+            }
+        }
+    }
+    return t0 <= t1;
+}
+
+inline bool finiteSeg(const OkSeg &s)
+{
+    return std::isfinite(s.x1) && std::isfinite(s.y1) && std::isfinite(s.x2) && std::isfinite(s.y2);
+}
+} // namespace okgrid
+
+// Builds the grid with the given cell edge.  `max_cells` bounds nx*ny (the cell edge is enlarged if needed).
+inline OkGridHost okBuildGrid(const OkSeg *segs, const size_t num_segments, float cell, const size_t max_cells = 1U << 20)
+{
+    OkGridHost out;
+    double     minx = 1e300, miny = 1e300, maxx = -1e300, maxy = -1e300, maxabs = 0.0;
+    size_t     finite = 0;
+    for (size_t i = 0; i < num_segments; ++i)
+    {
+        if (!okgrid::finiteSeg(segs[i]))
+            continue;
+        ++finite;
+        const double xs[2] = {segs[i].x1, segs[i].x2}, ys[2] = {segs[i].y1, segs[i].y2};
+        for (int k = 0; k < 2; ++k)
+        {
+            minx   = std::fmin(minx, xs[k]);
+            maxx   = std::fmax(maxx, xs[k]);
+            miny   = std::fmin(miny, ys[k]);
+            maxy   = std::fmax(maxy, ys[k]);
+            maxabs = std::fmax(maxabs, std::fmax(std::fabs(xs[k]), std::fabs(ys[k])));
+        }
+    }
+    if (finite == 0)
+    {
+        minx = miny = 0.0;
+        maxx = maxy = 1.0;
+    }
+    // margin: 1/8 px, or 64 ulp of the largest coordinate if that is larger (keeps the argument valid for
+    // segment sets far from the origin)
+    const double ulp    = std::ldexp(1.0, static_cast<int>(std::floor(std::log2(std::fmax(maxabs, 1.0)))) - 23);
+    const double margin = std::fmax(0.125, 64.0 * ulp);
+    out.margin          = static_cast<float>(margin);
+    const double pad    = 2.0 * margin;
+    const double w = (maxx - minx) + 2.0 * pad, h = (maxy - miny) + 2.0 * pad;
+    if (!(cell > 0.F))
+        cell = 16.F;
+    double c = cell;
+    while (std::ceil(w / c) * std::ceil(h / c) > static_cast<double>(max_cells))
+        c *= 1.25;
+    out.g.cell     = static_cast<float>(c);
+    out.g.inv_cell = 1.0F / out.g.cell;
+    out.g.nx       = static_cast<int>(std::ceil(w / out.g.cell));
+    out.g.ny       = static_cast<int>(std::ceil(h / out.g.cell));
+    if (out.g.nx < 1)
+        out.g.nx = 1;
+    if (out.g.ny < 1)
+        out.g.ny = 1;
+    out.g.x0 = static_cast<float>(minx - pad);
+    out.g.y0 = static_cast<float>(miny - pad);
+    // upper corner as the traversal computes cell boundaries: x0 + n*cell in fp32
+    out.g.x1 = out.g.x0 + static_cast<float>(out.g.nx) * out.g.cell;
+    out.g.y1 = out.g.y0 + static_cast<float>(out.g.ny) * out.g.cell;
+
+    const size_t          ncell = out.numCells();
+    std::vector<uint32_t> count(ncell, 0U);
+    const double          x0 = out.g.x0, y0 = out.g.y0, cd = out.g.cell;
+    auto cellRange = [&](const OkSeg &s, int &ix0, int &ix1, int &iy0, int &iy1) {
+        const double lx = std::fmin(s.x1, s.x2) - margin, hx = std::fmax(s.x1, s.x2) + margin;
+        const double ly = std::fmin(s.y1, s.y2) - margin, hy = std::fmax(s.y1, s.y2) + margin;
+        ix0 = static_cast<int>(std::floor((lx - x0) / cd)) - 1; // one extra cell absorbs fp32-vs-fp64 boundary drift
+        ix1 = static_cast<int>(std::floor((hx - x0) / cd)) + 1;
+        iy0 = static_cast<int>(std::floor((ly - y0) / cd)) - 1;
+        iy1 = static_cast<int>(std::floor((hy - y0) / cd)) + 1;
+        ix0 = ix0 < 0 ? 0 : ix0;
+        iy0 = iy0 < 0 ? 0 : iy0;
+        ix1 = ix1 >= out.g.nx ? out.g.nx - 1 : ix1;
+        iy1 = iy1 >= out.g.ny ? out.g.ny - 1 : iy1;
+    };
+    // cell box in the traversal's own fp32 arithmetic (x0 + i*cell), inflated by the margin
+    auto touches = [&](const OkSeg &s, const int ix, const int iy) {
+        const double lx = static_cast<double>(out.g.x0 + static_cast<float>(ix) * out.g.cell) - margin;
+        const double hx = static_cast<double>(out.g.x0 + static_cast<float>(ix + 1) * out.g.cell) + margin;
+        const double ly = static_cast<double>(out.g.y0 + static_cast<float>(iy) * out.g.cell) - margin;
+        const double hy = static_cast<double>(out.g.y0 + static_cast<float>(iy + 1) * out.g.cell) + margin;
+        return okgrid::segmentTouchesBox(s.x1, s.y1, s.x2, s.y2, lx, ly, hx, hy);
+    };
+    for (int pass = 0; pass < 2; ++pass)
+    {
+        if (pass == 1)
+        {
+            out.start.assign(ncell + 1, 0U);
+            for (size_t cidx = 0; cidx < ncell; ++cidx)
+            {
+                out.start[cidx + 1] = out.start[cidx] + count[cidx];
+                if (count[cidx] > out.max_count)
+                    out.max_count = count[cidx];
+            }
+            out.refs.assign(out.start[ncell], 0U);
+            std::fill(count.begin(), count.end(), 0U);
+        }
+        for (size_t i = 0; i < num_segments; ++i)
+        {
+            const OkSeg &s = segs[i];
+            if (!okgrid::finiteSeg(s))
+                continue; // can never produce a valid hit: every comparison on NaN/Inf quotients fails
+            int ix0, ix1, iy0, iy1;
+            cellRange(s, ix0, ix1, iy0, iy1);
+            for (int iy = iy0; iy <= iy1; ++iy)
+            {
+                for (int ix = ix0; ix <= ix1; ++ix)
+                {
+                    if (!touches(s, ix, iy))
+                        continue;
+                    const size_t cidx = static_cast<size_t>(iy) * out.g.nx + ix;
+                    if (pass == 1)
+                        out.refs[out.start[cidx] + count[cidx]] = static_cast<uint32_t>(i);
+                    ++count[cidx];
+                }
+            }
+        }
+    }
+    return out;
+}
+
+// Picks the cell edge: `requested` if > 0, else the default; enlarged until the compact LDS image fits
+// `lds_budget` bytes (if it ever does).  Returns the grid; `*fits_lds` tells whether the compact form fits.
+inline OkGridHost
+okBuildGridAuto(const OkSeg *segs, const size_t num_segments, const float requested, const size_t lds_budget, bool *fits_lds)
+{
+    float      cell = requested > 0.F ? requested : 16.F;
+    OkGridHost g;
+    for (int attempt = 0; attempt < 24; ++attempt)
+    {
+        g = okBuildGrid(segs, num_segments, cell);
+        if (g.fits16(num_segments) && g.imageBytes16(num_segments) <= lds_budget)
+        {
+            *fits_lds = true;
+            return g;
+        }
+        if (num_segments * 16U + 64U > lds_budget || num_segments > 65535U)
+            break; // the segments alone do not fit: no cell size will help
+        cell *= 1.25F;
+    }
+    *fits_lds = false;
+    return okBuildGrid(segs, num_segments, requested > 0.F ? requested : 16.F);
+}

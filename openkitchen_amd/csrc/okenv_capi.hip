@@ -1,0 +1,846 @@
+// okenv_capi.hip -- implementation of the C ABI declared in include/okenv.h.
+//
+// Host side of the batched Environment step: owns the device-resident struct-of-arrays state, builds and
+// uploads the uniform grid, chooses the launch geometry and enqueues the kernels of okenv_kernels.h on the
+// handle's HIP stream.  There is no CPU fallback anywhere in this file: without a usable GPU
+// okenv_create fails with OKENV_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/okenv.h"
+#include "Environment/RaceTrack.h"
+#include "ok_grid.h"
+#include "okenv_kernels.h"
+
+namespace
+{
+thread_local std::string g_create_error = "";
+
+constexpr size_t kLdsBudget = 160U * 1024U; // one workgroup may take the whole CU's LDS on gfx950
+
+struct EventPair
+{
+    hipEvent_t start, stop;
+};
+} // namespace
+
+struct okenv
+{
+    int         device{0};
+    hipStream_t stream{nullptr};
+    bool        own_stream{true};
+    int         N{0}, R{0}, S{0}, G{1}, rays_per_lane{1};
+    uint32_t    flags{0};
+    int         grid_mode{kGridLds};
+    OkGridHost  grid;
+    size_t      image_bytes{0}, off_hdr{0}, off_refs{0};
+    void       *d_image{nullptr};
+    OkSeg      *d_segs{nullptr};
+    uint32_t   *d_refs32{nullptr}, *d_start{nullptr};
+    float      *d_ray_deg{nullptr};
+    float       sensor_offset{0.F};
+    float      *d_cx{nullptr}, *d_cy{nullptr}, *d_chead{nullptr};
+    int         P{0};
+    OkDeviceState st{};
+    std::vector<void *> allocations;
+    int         block_threads{1024}, grid_blocks{1};
+    std::string last_error;
+    bool        timing{false};
+    std::vector<EventPair> events;      // recorded pairs awaiting resolution
+    std::vector<EventPair> event_pool;  // reusable pairs
+};
+
+struct okenv_track
+{
+    std::unique_ptr<RaceTrack> track;
+    std::vector<Segment2d>     segments;
+};
+
+namespace
+{
+int fail(okenv *h, const int code, const std::string &msg)
+{
+    if (h)
+        h->last_error = msg;
+    else
+        g_create_error = msg;
+    return code;
+}
+
+#define OK_HIP(h, call)                                                                                                \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        const hipError_t e_ = (call);                                                                                  \
+        if (e_ != hipSuccess)                                                                                          \
+            return fail((h), OKENV_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+
+template <class T>
+int devAlloc(okenv *h, T **out, const size_t count)
+{
+    void *p = nullptr;
+    OK_HIP(h, hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    OK_HIP(h, hipMemsetAsync(p, 0, std::max<size_t>(count, 1) * sizeof(T), h->stream));
+    h->allocations.push_back(p);
+    *out = static_cast<T *>(p);
+    return OKENV_OK;
+}
+
+int pow2ceil(int v)
+{
+    int p = 1;
+    while (p < v)
+        p <<= 1;
+    return p;
+}
+
+struct FieldDesc
+{
+    void  *ptr;
+    size_t bytes;
+};
+
+FieldDesc fieldOf(okenv *h, const int f)
+{
+    const size_t N = h->N, NR = static_cast<size_t>(h->N) * h->R;
+    auto        &s = h->st;
+    switch (f)
+    {
+    case OKENV_F_POS_X: return {s.pos_x, 4 * N};
+    case OKENV_F_POS_Y: return {s.pos_y, 4 * N};
+    case OKENV_F_ROT: return {s.rot, 4 * N};
+    case OKENV_F_SPEED: return {s.speed, 4 * N};
+    case OKENV_F_ACC: return {s.acc, 4 * N};
+    case OKENV_F_THROTTLE: return {s.thr, 4 * N};
+    case OKENV_F_STEER: return {s.steer, 4 * N};
+    case OKENV_F_MODE: return {s.mode, N};
+    case OKENV_F_CRASHED: return {s.crashed, N};
+    case OKENV_F_TIMED_OUT: return {s.timed_out, N};
+    case OKENV_F_DISP_CTR: return {s.disp_ctr, 4 * N};
+    case OKENV_F_DISP_X: return {s.disp_x, 4 * N};
+    case OKENV_F_DISP_Y: return {s.disp_y, 4 * N};
+    case OKENV_F_DISP_TO: return {s.disp_to, N};
+    case OKENV_F_HIT_X: return {s.hit_x, 4 * NR};
+    case OKENV_F_HIT_Y: return {s.hit_y, 4 * NR};
+    case OKENV_F_REL_X: return {s.rel_x, 4 * NR};
+    case OKENV_F_REL_Y: return {s.rel_y, 4 * NR};
+    case OKENV_F_DIST: return {s.dist, 4 * NR};
+    default: return {nullptr, 0};
+    }
+}
+
+OkStepParams baseParams(okenv *h)
+{
+    OkStepParams p{};
+    p.st            = h->st;
+    p.N             = h->N;
+    p.R             = h->R;
+    p.G             = h->G;
+    p.rays_per_lane = h->rays_per_lane;
+    p.ray_deg       = h->d_ray_deg;
+    p.sensor_offset = h->sensor_offset;
+    p.image         = static_cast<const uint8_t *>(h->d_image);
+    p.image_bytes   = static_cast<uint32_t>(h->image_bytes);
+    p.off_hdr       = static_cast<uint32_t>(h->off_hdr);
+    p.off_refs      = static_cast<uint32_t>(h->off_refs);
+    p.geom          = h->grid.g;
+    p.g_segs        = h->d_segs;
+    p.g_refs32      = h->d_refs32;
+    p.g_start       = h->d_start;
+    p.S             = h->S;
+    p.n_steps       = 1;
+    p.do_move       = 1;
+    p.action_source = kActionsStored;
+    p.cx            = h->d_cx;
+    p.cy            = h->d_cy;
+    p.chead         = h->d_chead;
+    p.P             = h->P;
+    return p;
+}
+
+int beginTiming(okenv *h, EventPair *ev)
+{
+    if (!h->timing)
+        return OKENV_OK;
+    if (!h->event_pool.empty())
+    {
+        *ev = h->event_pool.back();
+        h->event_pool.pop_back();
+    }
+    else
+    {
+        OK_HIP(h, hipEventCreate(&ev->start));
+        OK_HIP(h, hipEventCreate(&ev->stop));
+    }
+    OK_HIP(h, hipEventRecord(ev->start, h->stream));
+    return OKENV_OK;
+}
+
+int endTiming(okenv *h, const EventPair &ev)
+{
+    if (!h->timing)
+        return OKENV_OK;
+    OK_HIP(h, hipEventRecord(ev.stop, h->stream));
+    h->events.push_back(ev);
+    return OKENV_OK;
+}
+
+int launchStep(okenv *h, const OkStepParams &p)
+{
+    OK_HIP(h, hipSetDevice(h->device));
+    EventPair ev{};
+    int       rc = beginTiming(h, &ev);
+    if (rc != OKENV_OK)
+        return rc;
+    const dim3 grid(h->grid_blocks), block(h->block_threads);
+    switch (h->grid_mode)
+    {
+    case kGridLds:
+        hipLaunchKernelGGL(okStepKernel<kGridLds>, grid, block, h->image_bytes, h->stream, p);
+        break;
+    case kGridGlobal:
+        hipLaunchKernelGGL(okStepKernel<kGridGlobal>, grid, block, 0, h->stream, p);
+        break;
+    default:
+        hipLaunchKernelGGL(okStepKernel<kGridBrute>, grid, block, 0, h->stream, p);
+        break;
+    }
+    OK_HIP(h, hipGetLastError());
+    return endTiming(h, ev);
+}
+
+int copyAny(okenv *h, void *dst, const void *src, const size_t bytes)
+{
+    if (bytes == 0)
+        return OKENV_OK;
+    OK_HIP(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, h->stream));
+    return OKENV_OK;
+}
+} // namespace
+
+extern "C"
+{
+    const char *okenv_last_error(okenv_t h)
+    {
+        return h ? h->last_error.c_str() : g_create_error.c_str();
+    }
+
+    int okenv_create(okenv_t     *out,
+                     const float *segments_xyxy,
+                     int32_t      num_segments,
+                     int32_t      num_agents,
+                     int32_t      num_rays,
+                     const float *ray_angles_deg,
+                     int32_t      device,
+                     uint32_t     flags,
+                     float        grid_cell)
+    {
+        if (!out)
+            return fail(nullptr, OKENV_ERR_INVALID, "okenv_create: out is NULL");
+        *out = nullptr;
+        // TrackSegments asserts num_segments > 0 (TrackSegments.cu:72); CollisionChecker needs >= 1 agent with >= 1 ray
+        if (!segments_xyxy || num_segments <= 0)
+            return fail(nullptr, OKENV_ERR_INVALID, "okenv_create: need at least one segment");
+        if (num_agents <= 0 || num_rays <= 0 || !ray_angles_deg)
+            return fail(nullptr, OKENV_ERR_INVALID, "okenv_create: need at least one agent and one ray");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            return fail(nullptr, OKENV_ERR_NO_DEVICE, "okenv_create: no HIP device available (there is no CPU fallback)");
+        if (device < 0 || device >= ndev)
+            return fail(nullptr, OKENV_ERR_INVALID, "okenv_create: device ordinal out of range");
+
+        std::unique_ptr<okenv> hp(new okenv);
+        okenv                 *h = hp.get();
+        h->device                = device;
+        h->N                     = num_agents;
+        h->R                     = num_rays;
+        h->S                     = num_segments;
+        h->flags                 = flags;
+        OK_HIP(nullptr, hipSetDevice(device));
+        OK_HIP(nullptr, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+
+        // lanes per agent
+        h->G             = pow2ceil(num_rays) > 64 ? 64 : pow2ceil(num_rays);
+        h->rays_per_lane = (num_rays + h->G - 1) / h->G;
+
+        // ---- grid ------------------------------------------------------------------------------------
+        const OkSeg *segs = reinterpret_cast<const OkSeg *>(segments_xyxy);
+        bool         fits = false;
+        h->grid           = okBuildGridAuto(segs, static_cast<size_t>(num_segments), grid_cell, kLdsBudget, &fits);
+        if (flags & OKENV_FLAG_BRUTE_FORCE)
+            h->grid_mode = kGridBrute;
+        else if (!fits || (flags & OKENV_FLAG_FORCE_GLOBAL_GRID))
+            h->grid_mode = kGridGlobal;
+        else
+            h->grid_mode = kGridLds;
+
+        int rc;
+        if ((rc = devAlloc(h, &h->d_segs, static_cast<size_t>(num_segments))) != OKENV_OK)
+            return fail(nullptr, rc, h->last_error);
+        OK_HIP(nullptr, hipMemcpyAsync(h->d_segs, segs, sizeof(OkSeg) * num_segments, hipMemcpyHostToDevice, h->stream));
+        if (h->grid_mode == kGridLds)
+        {
+            const size_t seg_b = OkGridHost::align16(static_cast<size_t>(num_segments) * 16U);
+            const size_t hdr_b = OkGridHost::align16(h->grid.numCells() * 4U);
+            const size_t ref_b = OkGridHost::align16(h->grid.refs.size() * 2U);
+            h->off_hdr         = seg_b;
+            h->off_refs        = seg_b + hdr_b;
+            h->image_bytes     = seg_b + hdr_b + ref_b;
+            std::vector<uint8_t> img(h->image_bytes, 0);
+            std::memcpy(img.data(), segs, static_cast<size_t>(num_segments) * 16U);
+            uint32_t *hdr = reinterpret_cast<uint32_t *>(img.data() + h->off_hdr);
+            for (size_t c = 0; c < h->grid.numCells(); ++c)
+                hdr[c] = (h->grid.start[c] << 16) | (h->grid.start[c + 1] - h->grid.start[c]);
+            uint16_t *refs = reinterpret_cast<uint16_t *>(img.data() + h->off_refs);
+            for (size_t k = 0; k < h->grid.refs.size(); ++k)
+                refs[k] = static_cast<uint16_t>(h->grid.refs[k]);
+            uint8_t *dimg = nullptr;
+            if ((rc = devAlloc(h, &dimg, h->image_bytes)) != OKENV_OK)
+                return fail(nullptr, rc, h->last_error);
+            h->d_image = dimg;
+            OK_HIP(nullptr, hipMemcpyAsync(dimg, img.data(), h->image_bytes, hipMemcpyHostToDevice, h->stream));
+            OK_HIP(nullptr, hipStreamSynchronize(h->stream)); // img goes out of scope
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepKernel<kGridLds>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->image_bytes)));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okDebugCastKernel<kGridLds>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->image_bytes)));
+        }
+        else if (h->grid_mode == kGridGlobal)
+        {
+            if ((rc = devAlloc(h, &h->d_refs32, h->grid.refs.size())) != OKENV_OK ||
+                (rc = devAlloc(h, &h->d_start, h->grid.start.size())) != OKENV_OK)
+                return fail(nullptr, rc, h->last_error);
+            OK_HIP(nullptr, hipMemcpyAsync(h->d_refs32, h->grid.refs.data(), 4U * h->grid.refs.size(), hipMemcpyHostToDevice, h->stream));
+            OK_HIP(nullptr, hipMemcpyAsync(h->d_start, h->grid.start.data(), 4U * h->grid.start.size(), hipMemcpyHostToDevice, h->stream));
+        }
+
+        // ---- state -----------------------------------------------------------------------------------
+        const size_t N = num_agents, NR = static_cast<size_t>(num_agents) * num_rays;
+        auto        &s = h->st;
+        if ((rc = devAlloc(h, &s.pos_x, N)) || (rc = devAlloc(h, &s.pos_y, N)) || (rc = devAlloc(h, &s.rot, N)) ||
+            (rc = devAlloc(h, &s.speed, N)) || (rc = devAlloc(h, &s.acc, N)) || (rc = devAlloc(h, &s.thr, N)) ||
+            (rc = devAlloc(h, &s.steer, N)) || (rc = devAlloc(h, &s.mode, N)) || (rc = devAlloc(h, &s.crashed, N)) ||
+            (rc = devAlloc(h, &s.timed_out, N)) || (rc = devAlloc(h, &s.disp_to, N)) || (rc = devAlloc(h, &s.disp_ctr, N)) ||
+            (rc = devAlloc(h, &s.disp_x, N)) || (rc = devAlloc(h, &s.disp_y, N)) || (rc = devAlloc(h, &s.hit_x, NR)) ||
+            (rc = devAlloc(h, &s.hit_y, NR)) || (rc = devAlloc(h, &s.rel_x, NR)) || (rc = devAlloc(h, &s.rel_y, NR)) ||
+            (rc = devAlloc(h, &s.dist, NR)) || (rc = devAlloc(h, &h->d_ray_deg, static_cast<size_t>(num_rays))))
+            return fail(nullptr, rc, h->last_error);
+        OK_HIP(nullptr, hipMemcpyAsync(h->d_ray_deg, ray_angles_deg, 4U * num_rays, hipMemcpyHostToDevice, h->stream));
+
+        // ---- launch geometry -------------------------------------------------------------------------
+        // Spread small populations over the CUs: aim for >= 256 workgroups before growing them to 1024 lanes.
+        const long total_lanes = static_cast<long>(num_agents) * h->G;
+        long       per_block   = (total_lanes + 255) / 256;
+        per_block              = ((per_block + 63) / 64) * 64;
+        if (per_block < 64)
+            per_block = 64;
+        if (per_block > 1024)
+            per_block = 1024;
+        h->block_threads = static_cast<int>(per_block);
+        h->grid_blocks   = static_cast<int>((total_lanes + per_block - 1) / per_block);
+        OK_HIP(nullptr, hipStreamSynchronize(h->stream));
+        *out = hp.release();
+        return OKENV_OK;
+    }
+
+    int okenv_destroy(okenv_t h)
+    {
+        if (!h)
+            return OKENV_OK;
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+        for (void *p : h->allocations)
+            (void)hipFree(p);
+        for (auto &e : h->events)
+        {
+            (void)hipEventDestroy(e.start);
+            (void)hipEventDestroy(e.stop);
+        }
+        for (auto &e : h->event_pool)
+        {
+            (void)hipEventDestroy(e.start);
+            (void)hipEventDestroy(e.stop);
+        }
+        if (h->own_stream && h->stream)
+            (void)hipStreamDestroy(h->stream);
+        delete h;
+        return OKENV_OK;
+    }
+
+    int okenv_get_info(okenv_t h, okenv_info *out)
+    {
+        if (!h || !out)
+            return fail(h, OKENV_ERR_INVALID, "okenv_get_info: NULL argument");
+        out->num_agents      = h->N;
+        out->num_rays        = h->R;
+        out->num_segments    = h->S;
+        out->grid_nx         = h->grid.g.nx;
+        out->grid_ny         = h->grid.g.ny;
+        out->grid_cell       = h->grid.g.cell;
+        out->grid_refs       = static_cast<int32_t>(h->grid.refs.size());
+        out->grid_in_lds     = h->grid_mode == kGridLds ? 1 : 0;
+        out->lds_bytes       = h->grid_mode == kGridLds ? static_cast<int32_t>(h->image_bytes) : 0;
+        out->block_threads   = h->block_threads;
+        out->grid_blocks     = h->grid_blocks;
+        out->lanes_per_agent = h->G;
+        out->device          = h->device;
+        return OKENV_OK;
+    }
+
+    int okenv_set_sensor_offset(okenv_t h, float offset)
+    {
+        if (!h)
+            return OKENV_ERR_INVALID;
+        h->sensor_offset = offset;
+        return OKENV_OK;
+    }
+
+    int okenv_set_centerline(okenv_t h, const float *x, const float *y, const float *heading_deg, int32_t num_points)
+    {
+        if (!h || !x || !y || !heading_deg || num_points <= 0)
+            return fail(h, OKENV_ERR_INVALID, "okenv_set_centerline: bad argument");
+        OK_HIP(h, hipSetDevice(h->device));
+        int rc;
+        if ((rc = devAlloc(h, &h->d_cx, static_cast<size_t>(num_points))) || (rc = devAlloc(h, &h->d_cy, static_cast<size_t>(num_points))) ||
+            (rc = devAlloc(h, &h->d_chead, static_cast<size_t>(num_points))))
+            return rc;
+        h->P = num_points;
+        OK_HIP(h, hipMemcpyAsync(h->d_cx, x, 4U * num_points, hipMemcpyDefault, h->stream));
+        OK_HIP(h, hipMemcpyAsync(h->d_cy, y, 4U * num_points, hipMemcpyDefault, h->stream));
+        OK_HIP(h, hipMemcpyAsync(h->d_chead, heading_deg, 4U * num_points, hipMemcpyDefault, h->stream));
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        return OKENV_OK;
+    }
+
+    int okenv_set_stream(okenv_t h, void *hip_stream)
+    {
+        if (!h)
+            return OKENV_ERR_INVALID;
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->own_stream && h->stream)
+            (void)hipStreamDestroy(h->stream);
+        h->stream     = static_cast<hipStream_t>(hip_stream);
+        h->own_stream = false;
+        return OKENV_OK;
+    }
+
+    int okenv_sync(okenv_t h)
+    {
+        if (!h)
+            return OKENV_ERR_INVALID;
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        return OKENV_OK;
+    }
+
+    int okenv_set_field(okenv_t h, int32_t field, const void *src)
+    {
+        if (!h || !src)
+            return fail(h, OKENV_ERR_INVALID, "okenv_set_field: NULL argument");
+        const FieldDesc d = fieldOf(h, field);
+        if (!d.ptr)
+            return fail(h, OKENV_ERR_INVALID, "okenv_set_field: unknown field");
+        int rc = copyAny(h, d.ptr, src, d.bytes);
+        if (rc != OKENV_OK)
+            return rc;
+        OK_HIP(h, hipStreamSynchronize(h->stream)); // the caller may reuse src immediately
+        return OKENV_OK;
+    }
+
+    int okenv_get_field(okenv_t h, int32_t field, void *dst)
+    {
+        if (!h || !dst)
+            return fail(h, OKENV_ERR_INVALID, "okenv_get_field: NULL argument");
+        const FieldDesc d = fieldOf(h, field);
+        if (!d.ptr)
+            return fail(h, OKENV_ERR_INVALID, "okenv_get_field: unknown field");
+        int rc = copyAny(h, dst, d.ptr, d.bytes);
+        if (rc != OKENV_OK)
+            return rc;
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        return OKENV_OK;
+    }
+
+    static int moveState(okenv_t h, const okenv_state_view *v, const bool upload)
+    {
+        if (!h || !v)
+            return fail(h, OKENV_ERR_INVALID, "state view is NULL");
+        const size_t N = h->N;
+        auto        &s = h->st;
+        struct Item
+        {
+            void  *dev;
+            void  *host;
+            size_t bytes;
+        };
+        const Item items[] = {{s.pos_x, v->pos_x, 4 * N},       {s.pos_y, v->pos_y, 4 * N},     {s.rot, v->rot, 4 * N},
+                              {s.speed, v->speed, 4 * N},       {s.acc, v->acc, 4 * N},         {s.thr, v->throttle, 4 * N},
+                              {s.steer, v->steer, 4 * N},       {s.mode, v->mode, N},           {s.crashed, v->crashed, N},
+                              {s.timed_out, v->timed_out, N},   {s.disp_ctr, v->disp_ctr, 4 * N}, {s.disp_x, v->disp_x, 4 * N},
+                              {s.disp_y, v->disp_y, 4 * N},     {s.disp_to, v->disp_timed_out, N}};
+        for (const Item &it : items)
+        {
+            if (!it.host)
+                continue;
+            const int rc = upload ? copyAny(h, it.dev, it.host, it.bytes) : copyAny(h, it.host, it.dev, it.bytes);
+            if (rc != OKENV_OK)
+                return rc;
+        }
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        return OKENV_OK;
+    }
+
+    int okenv_upload_state(okenv_t h, const okenv_state_view *host_view)
+    {
+        return moveState(h, host_view, true);
+    }
+
+    int okenv_download_state(okenv_t h, const okenv_state_view *host_view)
+    {
+        return moveState(h, host_view, false);
+    }
+
+    int okenv_set_actions(okenv_t h, const float *throttle, const float *steer)
+    {
+        if (!h || !throttle || !steer)
+            return fail(h, OKENV_ERR_INVALID, "okenv_set_actions: NULL argument");
+        int rc;
+        if ((rc = copyAny(h, h->st.thr, throttle, 4U * h->N)) || (rc = copyAny(h, h->st.steer, steer, 4U * h->N)))
+            return rc;
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        return OKENV_OK;
+    }
+
+    int okenv_reset_agents(okenv_t h, const int32_t *idx, const float *x, const float *y, const float *rot_deg, int32_t n)
+    {
+        if (!h || n < 0 || (n > 0 && (!idx || !x || !y || !rot_deg)))
+            return fail(h, OKENV_ERR_INVALID, "okenv_reset_agents: bad argument");
+        if (n == 0)
+            return OKENV_OK;
+        OK_HIP(h, hipSetDevice(h->device));
+        // one staging buffer: idx | x | y | rot
+        const size_t bytes = static_cast<size_t>(n) * 16U;
+        void        *stage = nullptr;
+        OK_HIP(h, hipMallocAsync(&stage, bytes, h->stream));
+        char *b = static_cast<char *>(stage);
+        OK_HIP(h, hipMemcpyAsync(b, idx, 4U * n, hipMemcpyHostToDevice, h->stream));
+        OK_HIP(h, hipMemcpyAsync(b + 4U * n, x, 4U * n, hipMemcpyHostToDevice, h->stream));
+        OK_HIP(h, hipMemcpyAsync(b + 8U * n, y, 4U * n, hipMemcpyHostToDevice, h->stream));
+        OK_HIP(h, hipMemcpyAsync(b + 12U * n, rot_deg, 4U * n, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(okResetKernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->st, reinterpret_cast<const int32_t *>(b),
+                           reinterpret_cast<const float *>(b + 4U * n), reinterpret_cast<const float *>(b + 8U * n),
+                           reinterpret_cast<const float *>(b + 12U * n), n, h->N);
+        OK_HIP(h, hipGetLastError());
+        OK_HIP(h, hipFreeAsync(stage, h->stream));
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        return OKENV_OK;
+    }
+
+    int okenv_get_hits(okenv_t h, float *out_xy)
+    {
+        if (!h || !out_xy)
+            return fail(h, OKENV_ERR_INVALID, "okenv_get_hits: NULL argument");
+        const size_t       NR = static_cast<size_t>(h->N) * h->R;
+        std::vector<float> rx(NR), ry(NR);
+        int                rc;
+        if ((rc = copyAny(h, rx.data(), h->st.rel_x, 4U * NR)) || (rc = copyAny(h, ry.data(), h->st.rel_y, 4U * NR)))
+            return rc;
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        for (size_t k = 0; k < NR; ++k)
+        {
+            out_xy[2 * k]     = rx[k];
+            out_xy[2 * k + 1] = ry[k];
+        }
+        return OKENV_OK;
+    }
+
+    int okenv_get_distances(okenv_t h, float *out)
+    {
+        return okenv_get_field(h, OKENV_F_DIST, out);
+    }
+
+    int okenv_get_flags(okenv_t h, uint8_t *out)
+    {
+        if (!h || !out)
+            return fail(h, OKENV_ERR_INVALID, "okenv_get_flags: NULL argument");
+        std::vector<uint8_t> c(h->N), t(h->N);
+        int                  rc;
+        if ((rc = copyAny(h, c.data(), h->st.crashed, h->N)) || (rc = copyAny(h, t.data(), h->st.timed_out, h->N)))
+            return rc;
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        for (int i = 0; i < h->N; ++i)
+            out[i] = static_cast<uint8_t>((c[i] ? 1 : 0) | (t[i] ? 2 : 0));
+        return OKENV_OK;
+    }
+
+    int okenv_step(okenv_t h, int32_t n_steps)
+    {
+        if (!h || n_steps < 0)
+            return fail(h, OKENV_ERR_INVALID, "okenv_step: bad argument");
+        if (n_steps == 0)
+            return OKENV_OK;
+        OkStepParams p = baseParams(h);
+        p.n_steps      = n_steps;
+        return launchStep(h, p);
+    }
+
+    int okenv_collide(okenv_t h)
+    {
+        if (!h)
+            return OKENV_ERR_INVALID;
+        OkStepParams p = baseParams(h);
+        p.do_move      = 0;
+        return launchStep(h, p);
+    }
+
+    int okenv_rollout_random(okenv_t h, int32_t n_steps, uint32_t seed, uint32_t agent_base, uint32_t step_base)
+    {
+        if (!h || n_steps < 0)
+            return fail(h, OKENV_ERR_INVALID, "okenv_rollout_random: bad argument");
+        if (h->P <= 0)
+            return fail(h, OKENV_ERR_STATE, "okenv_rollout_random: call okenv_set_centerline first");
+        if (n_steps == 0)
+            return OKENV_OK;
+        OkStepParams p  = baseParams(h);
+        p.n_steps       = n_steps;
+        p.action_source = kActionsPhiloxReset;
+        p.seed          = seed;
+        p.agent_base    = agent_base;
+        p.step_base     = step_base;
+        return launchStep(h, p);
+    }
+
+    int okenv_init_bench_state(okenv_t h, uint32_t agent_base, int32_t mode)
+    {
+        if (!h)
+            return OKENV_ERR_INVALID;
+        if (h->P <= 0)
+            return fail(h, OKENV_ERR_STATE, "okenv_init_bench_state: call okenv_set_centerline first");
+        OK_HIP(h, hipSetDevice(h->device));
+        hipLaunchKernelGGL(okInitBenchKernel, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->st, h->d_cx, h->d_cy, h->d_chead,
+                           h->P, h->N, h->R, agent_base, mode);
+        OK_HIP(h, hipGetLastError());
+        return OKENV_OK;
+    }
+
+    int okenv_nearest_track_idx(okenv_t h, const float *qx, const float *qy, int32_t n, int32_t *out)
+    {
+        if (!h || !out)
+            return fail(h, OKENV_ERR_INVALID, "okenv_nearest_track_idx: NULL argument");
+        if (h->P <= 0)
+            return fail(h, OKENV_ERR_STATE, "okenv_nearest_track_idx: call okenv_set_centerline first");
+        OK_HIP(h, hipSetDevice(h->device));
+        const bool agents = (qx == nullptr);
+        if (agents)
+            n = h->N;
+        if (n <= 0)
+            return OKENV_OK;
+        float   *dq  = nullptr;
+        int32_t *dout = nullptr;
+        OK_HIP(h, hipMallocAsync(reinterpret_cast<void **>(&dout), 4U * n, h->stream));
+        const float *dqx = h->st.pos_x, *dqy = h->st.pos_y;
+        if (!agents)
+        {
+            if (!qy)
+                return fail(h, OKENV_ERR_INVALID, "okenv_nearest_track_idx: qy is NULL");
+            OK_HIP(h, hipMallocAsync(reinterpret_cast<void **>(&dq), 8U * n, h->stream));
+            OK_HIP(h, hipMemcpyAsync(dq, qx, 4U * n, hipMemcpyDefault, h->stream));
+            OK_HIP(h, hipMemcpyAsync(dq + n, qy, 4U * n, hipMemcpyDefault, h->stream));
+            dqx = dq;
+            dqy = dq + n;
+        }
+        hipLaunchKernelGGL(okNearestIdxKernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_cx, h->d_cy, h->P, dqx, dqy, n, dout);
+        OK_HIP(h, hipGetLastError());
+        OK_HIP(h, hipMemcpyAsync(out, dout, 4U * n, hipMemcpyDefault, h->stream));
+        if (dq)
+            OK_HIP(h, hipFreeAsync(dq, h->stream));
+        OK_HIP(h, hipFreeAsync(dout, h->stream));
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        return OKENV_OK;
+    }
+
+    int okenv_set_timing(okenv_t h, int32_t enabled)
+    {
+        if (!h)
+            return OKENV_ERR_INVALID;
+        h->timing = enabled != 0;
+        return OKENV_OK;
+    }
+
+    int okenv_get_timing(okenv_t h, double *total_ms, uint64_t *launches)
+    {
+        if (!h || !total_ms || !launches)
+            return fail(h, OKENV_ERR_INVALID, "okenv_get_timing: NULL argument");
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        double sum = 0.0;
+        for (auto &e : h->events)
+        {
+            float ms = 0.F;
+            OK_HIP(h, hipEventElapsedTime(&ms, e.start, e.stop));
+            sum += ms;
+        }
+        *total_ms = sum;
+        *launches = h->events.size();
+        for (auto &e : h->events)
+            h->event_pool.push_back(e);
+        h->events.clear();
+        return OKENV_OK;
+    }
+
+    // ---- track ------------------------------------------------------------------------------------------
+
+    int okenv_track_load(okenv_track_t *out, const char *csv_path)
+    {
+        if (!out || !csv_path)
+            return fail(nullptr, OKENV_ERR_INVALID, "okenv_track_load: NULL argument");
+        *out = nullptr;
+        std::unique_ptr<okenv_track> t(new okenv_track);
+        t->track.reset(new RaceTrack(std::string(csv_path)));
+        if (!t->track->loadedOk())
+            return fail(nullptr, OKENV_ERR_IO, std::string("okenv_track_load: cannot read ") + csv_path);
+        // TrackSegments (TrackSegments.cu:6-42): LI, LO, RI, RO polylines, then closers LI, RI, LO, RO
+        const RaceTrack &rt   = *t->track;
+        auto             run = [&](const std::vector<Vec2d> &poly) {
+            for (size_t i = 0; i + 1 < poly.size(); ++i)
+                t->segments.push_back({poly[i].x, poly[i].y, poly[i + 1].x, poly[i + 1].y});
+        };
+        auto closer = [&](const std::vector<Vec2d> &poly) {
+            t->segments.push_back({poly.back().x, poly.back().y, poly.front().x, poly.front().y});
+        };
+        run(rt.left_bound_inner_);
+        run(rt.left_bound_outer_);
+        run(rt.right_bound_inner_);
+        run(rt.right_bound_outer_);
+        if (rt.left_bound_inner_.size() > 1)
+        {
+            closer(rt.left_bound_inner_);
+            closer(rt.right_bound_inner_);
+        }
+        if (rt.left_bound_outer_.size() > 1)
+        {
+            closer(rt.left_bound_outer_);
+            closer(rt.right_bound_outer_);
+        }
+        *out = t.release();
+        return OKENV_OK;
+    }
+
+    int okenv_track_free(okenv_track_t t)
+    {
+        delete t;
+        return OKENV_OK;
+    }
+
+    int32_t okenv_track_num_points(okenv_track_t t)
+    {
+        return t ? static_cast<int32_t>(t->track->track_data_points_.x_m.size()) : 0;
+    }
+
+    int32_t okenv_track_num_segments(okenv_track_t t)
+    {
+        return t ? static_cast<int32_t>(t->segments.size()) : 0;
+    }
+
+    int okenv_track_get(okenv_track_t t, int32_t which, float *out)
+    {
+        if (!t || !out)
+            return OKENV_ERR_INVALID;
+        const RaceTrack &rt  = *t->track;
+        const auto      &d   = rt.track_data_points_;
+        auto             vec = [&](const std::vector<float> &v) { std::memcpy(out, v.data(), v.size() * 4U); };
+        auto             pts = [&](const std::vector<Vec2d> &v) {
+            for (size_t i = 0; i < v.size(); ++i)
+            {
+                out[2 * i]     = v[i].x;
+                out[2 * i + 1] = v[i].y;
+            }
+        };
+        switch (which)
+        {
+        case 0: vec(d.x_m); break;
+        case 1: vec(d.y_m); break;
+        case 2: vec(d.w_tr_right_m); break;
+        case 3: vec(d.w_tr_left_m); break;
+        case 4: vec(rt.headings_); break;
+        case 5: pts(rt.left_bound_inner_); break;
+        case 6: pts(rt.left_bound_outer_); break;
+        case 7: pts(rt.right_bound_inner_); break;
+        case 8: pts(rt.right_bound_outer_); break;
+        default: return OKENV_ERR_INVALID;
+        }
+        return OKENV_OK;
+    }
+
+    int okenv_track_segments(okenv_track_t t, float *out_xyxy)
+    {
+        if (!t || !out_xyxy)
+            return OKENV_ERR_INVALID;
+        std::memcpy(out_xyxy, t->segments.data(), t->segments.size() * sizeof(Segment2d));
+        return OKENV_OK;
+    }
+
+    // ---- device self-checks ----------------------------------------------------------------------------------
+
+    int okenv_debug_sincos(int32_t device, const float *x, float *s, float *c, int32_t n)
+    {
+        if (!x || !s || !c || n < 0)
+            return fail(nullptr, OKENV_ERR_INVALID, "okenv_debug_sincos: bad argument");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            return fail(nullptr, OKENV_ERR_NO_DEVICE, "okenv_debug_sincos: no HIP device");
+        if (n == 0)
+            return OKENV_OK;
+        OK_HIP(nullptr, hipSetDevice(device));
+        float *d = nullptr;
+        OK_HIP(nullptr, hipMalloc(reinterpret_cast<void **>(&d), 12U * static_cast<size_t>(n)));
+        OK_HIP(nullptr, hipMemcpy(d, x, 4U * static_cast<size_t>(n), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(okDebugSincosKernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, d, d + n, d + 2 * static_cast<size_t>(n), n);
+        OK_HIP(nullptr, hipGetLastError());
+        OK_HIP(nullptr, hipMemcpy(s, d + n, 4U * static_cast<size_t>(n), hipMemcpyDeviceToHost));
+        OK_HIP(nullptr, hipMemcpy(c, d + 2 * static_cast<size_t>(n), 4U * static_cast<size_t>(n), hipMemcpyDeviceToHost));
+        OK_HIP(nullptr, hipFree(d));
+        return OKENV_OK;
+    }
+
+    int okenv_debug_cast_rays(okenv_t h, const float *ox, const float *oy, const float *angle_rad, int32_t n, float *out_t)
+    {
+        if (!h || !ox || !oy || !angle_rad || !out_t || n < 0)
+            return fail(h, OKENV_ERR_INVALID, "okenv_debug_cast_rays: bad argument");
+        if (n == 0)
+            return OKENV_OK;
+        OK_HIP(h, hipSetDevice(h->device));
+        float *d = nullptr;
+        OK_HIP(h, hipMallocAsync(reinterpret_cast<void **>(&d), 16U * static_cast<size_t>(n), h->stream));
+        OK_HIP(h, hipMemcpyAsync(d, ox, 4U * static_cast<size_t>(n), hipMemcpyHostToDevice, h->stream));
+        OK_HIP(h, hipMemcpyAsync(d + n, oy, 4U * static_cast<size_t>(n), hipMemcpyHostToDevice, h->stream));
+        OK_HIP(h, hipMemcpyAsync(d + 2 * static_cast<size_t>(n), angle_rad, 4U * static_cast<size_t>(n), hipMemcpyHostToDevice, h->stream));
+        const OkStepParams p      = baseParams(h);
+        const int          blocks = std::min(1024, (n + 1023) / 1024);
+        float             *dt     = d + 3 * static_cast<size_t>(n);
+        switch (h->grid_mode)
+        {
+        case kGridLds:
+            hipLaunchKernelGGL(okDebugCastKernel<kGridLds>, dim3(blocks), dim3(1024), h->image_bytes, h->stream, p, d, d + n,
+                               d + 2 * static_cast<size_t>(n), n, dt);
+            break;
+        case kGridGlobal:
+            hipLaunchKernelGGL(okDebugCastKernel<kGridGlobal>, dim3(blocks), dim3(1024), 0, h->stream, p, d, d + n,
+                               d + 2 * static_cast<size_t>(n), n, dt);
+            break;
+        default:
+            hipLaunchKernelGGL(okDebugCastKernel<kGridBrute>, dim3(blocks), dim3(1024), 0, h->stream, p, d, d + n,
+                               d + 2 * static_cast<size_t>(n), n, dt);
+            break;
+        }
+        OK_HIP(h, hipGetLastError());
+        OK_HIP(h, hipMemcpyAsync(out_t, dt, 4U * static_cast<size_t>(n), hipMemcpyDeviceToHost, h->stream));
+        OK_HIP(h, hipFreeAsync(d, h->stream));
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        return OKENV_OK;
+    }
+}

@@ -1,0 +1,203 @@
+"""Python host side of the batched Environment step: thin, typed wrappers over the C ABI.
+
+`Track` mirrors the reference's RaceTrack + TrackSegments (Environment/RaceTrack.h, TrackSegments.h) and
+`BatchedEnvironment` mirrors Environment's step surface (Environment/Environment.h:31-75) for N agents at
+once with device-resident state.  bench.py, the parity tests and the Python callers use these; the C++
+callers use the classes in include/Environment/.  All compute happens in libokenv.so on the GPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi as capi
+
+TRACK_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tracks")
+
+
+def track_path(name):
+    """Path of a bundled TUMFTM racetrack-database CSV (Austin, Silverstone, Monza, Spa)."""
+    p = name if name.endswith(".csv") else os.path.join(TRACK_DIR, name + ".csv")
+    if not os.path.exists(p):
+        raise FileNotFoundError(p)
+    return p
+
+
+def default_ray_fan(num_rays):
+    """angle_i = -70 + 140*i/(R-1) degrees, fp32 (generalises Agent.cpp:11-18)."""
+    if num_rays == 1:
+        return np.zeros(1, dtype=np.float32)
+    i = np.arange(num_rays, dtype=np.float32)
+    return (np.float32(-70.0) + np.float32(140.0) * i / np.float32(num_rays - 1)).astype(np.float32)
+
+
+class Track:
+    """RaceTrack(csv) + TrackSegments(track): centre line, headings, four boundary polylines, 4*P segments."""
+
+    KEYS = ["x", "y", "wr", "wl", "heading", "li", "lo", "ri", "ro"]
+
+    def __init__(self, name_or_path):
+        L = capi.load()
+        self.path = track_path(name_or_path)
+        h = C.c_void_p()
+        capi.check(L.okenv_track_load(C.byref(h), self.path.encode()))
+        try:
+            self.P = L.okenv_track_num_points(h)
+            self.S = L.okenv_track_num_segments(h)
+            for w, k in enumerate(self.KEYS):
+                a = np.zeros(self.P if w < 5 else 2 * self.P, dtype=np.float32)
+                capi.check(L.okenv_track_get(h, w, capi.ptr(a)))
+                setattr(self, k, a)
+            seg = np.zeros((self.S, 4), dtype=np.float32)
+            capi.check(L.okenv_track_segments(h, capi.ptr(seg)))
+            self.segments = seg
+        finally:
+            L.okenv_track_free(h)
+
+
+class BatchedEnvironment:
+    """N agents x R rays on one GPU.  State lives on the device; see include/okenv.h for field semantics."""
+
+    def __init__(self, segments, num_agents, ray_angles_deg, device=0, flags=0, grid_cell=0.0, centerline=None):
+        L = capi.load()
+        seg = np.ascontiguousarray(segments, dtype=np.float32).reshape(-1, 4)
+        rays = np.ascontiguousarray(ray_angles_deg, dtype=np.float32)
+        self.N, self.R, self.S = int(num_agents), int(rays.size), int(seg.shape[0])
+        self._h = C.c_void_p()
+        capi.check(L.okenv_create(C.byref(self._h), capi.ptr(seg), self.S, self.N, self.R, capi.ptr(rays), int(device),
+                                  int(flags), float(grid_cell)))
+        self._L = L
+        self.ray_angles_deg = rays
+        if centerline is not None:
+            self.set_centerline(*centerline)
+
+    @classmethod
+    def from_track(cls, track, num_agents, num_rays=None, ray_angles_deg=None, **kw):
+        rays = default_ray_fan(num_rays) if ray_angles_deg is None else ray_angles_deg
+        return cls(track.segments, num_agents, rays, centerline=(track.x, track.y, track.heading), **kw)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.okenv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- configuration ---------------------------------------------------------------------------
+    def info(self):
+        i = capi.OkenvInfo()
+        capi.check(self._L.okenv_get_info(self._h, C.byref(i)), self._h)
+        return {k: getattr(i, k) for k, _ in capi.OkenvInfo._fields_}
+
+    def set_centerline(self, x, y, heading_deg):
+        x, y, hd = [np.ascontiguousarray(a, dtype=np.float32) for a in (x, y, heading_deg)]
+        self.P = int(x.size)
+        capi.check(self._L.okenv_set_centerline(self._h, capi.ptr(x), capi.ptr(y), capi.ptr(hd), self.P), self._h)
+
+    def set_sensor_offset(self, off):
+        capi.check(self._L.okenv_set_sensor_offset(self._h, float(off)), self._h)
+
+    def set_stream(self, hip_stream_ptr):
+        capi.check(self._L.okenv_set_stream(self._h, C.c_void_p(hip_stream_ptr)), self._h)
+
+    def sync(self):
+        capi.check(self._L.okenv_sync(self._h), self._h)
+
+    # ---- state -----------------------------------------------------------------------------------
+    def set(self, field, values):
+        """values: numpy array (copied from host) or a torch device tensor of the field's dtype."""
+        if isinstance(values, np.ndarray) or not hasattr(values, "data_ptr"):
+            values = np.ascontiguousarray(values, dtype=capi.FIELD_DTYPE[field])
+            n = self.N * self.R if field in capi.PER_RAY else self.N
+            assert values.size == n, (capi.FIELD_NAMES[field], values.size, n)
+        capi.check(self._L.okenv_set_field(self._h, field, capi.ptr(values)), self._h)
+
+    def get(self, field, out=None):
+        n = self.N * self.R if field in capi.PER_RAY else self.N
+        if out is None:
+            out = np.zeros(n, dtype=capi.FIELD_DTYPE[field])
+        capi.check(self._L.okenv_get_field(self._h, field, capi.ptr(out)), self._h)
+        if isinstance(out, np.ndarray) and field in capi.PER_RAY:
+            return out.reshape(self.N, self.R)
+        return out
+
+    def snapshot(self):
+        return {capi.FIELD_NAMES[f]: self.get(f) for f in range(19)}
+
+    def set_actions(self, throttle, steer):
+        if isinstance(throttle, np.ndarray) or not hasattr(throttle, "data_ptr"):
+            throttle = np.ascontiguousarray(throttle, dtype=np.float32)
+            steer = np.ascontiguousarray(steer, dtype=np.float32)
+        capi.check(self._L.okenv_set_actions(self._h, capi.ptr(throttle), capi.ptr(steer)), self._h)
+
+    def reset_agents(self, idx, x, y, rot_deg):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        x, y, rot = [np.ascontiguousarray(a, dtype=np.float32) for a in (x, y, rot_deg)]
+        capi.check(self._L.okenv_reset_agents(self._h, capi.ptr(idx), capi.ptr(x), capi.ptr(y), capi.ptr(rot), idx.size),
+                   self._h)
+
+    def hits(self):
+        out = np.zeros((self.N, self.R, 2), dtype=np.float32)
+        capi.check(self._L.okenv_get_hits(self._h, capi.ptr(out)), self._h)
+        return out
+
+    def distances(self):
+        out = np.zeros((self.N, self.R), dtype=np.float32)
+        capi.check(self._L.okenv_get_distances(self._h, capi.ptr(out)), self._h)
+        return out
+
+    def flags(self):
+        out = np.zeros(self.N, dtype=np.uint8)
+        capi.check(self._L.okenv_get_flags(self._h, capi.ptr(out)), self._h)
+        return out
+
+    # ---- hot path --------------------------------------------------------------------------------
+    def step(self, n_steps=1):
+        capi.check(self._L.okenv_step(self._h, int(n_steps)), self._h)
+
+    def collide(self):
+        capi.check(self._L.okenv_collide(self._h), self._h)
+
+    def rollout_random(self, n_steps, seed, agent_base=0, step_base=0):
+        capi.check(self._L.okenv_rollout_random(self._h, int(n_steps), int(seed), int(agent_base), int(step_base)), self._h)
+
+    def init_bench_state(self, agent_base=0, mode=capi.MODE_VELOCITY):
+        capi.check(self._L.okenv_init_bench_state(self._h, int(agent_base), int(mode)), self._h)
+
+    def nearest_track_idx(self, qx=None, qy=None):
+        if qx is None:
+            out = np.zeros(self.N, dtype=np.int32)
+            capi.check(self._L.okenv_nearest_track_idx(self._h, None, None, 0, capi.ptr(out)), self._h)
+            return out
+        qx = np.ascontiguousarray(qx, dtype=np.float32)
+        qy = np.ascontiguousarray(qy, dtype=np.float32)
+        out = np.zeros(qx.size, dtype=np.int32)
+        capi.check(self._L.okenv_nearest_track_idx(self._h, capi.ptr(qx), capi.ptr(qy), qx.size, capi.ptr(out)), self._h)
+        return out
+
+    # ---- measurement / self-checks ------------------------------------------------------------------
+    def set_timing(self, enabled):
+        capi.check(self._L.okenv_set_timing(self._h, 1 if enabled else 0), self._h)
+
+    def get_timing(self):
+        ms, n = C.c_double(), C.c_uint64()
+        capi.check(self._L.okenv_get_timing(self._h, C.byref(ms), C.byref(n)), self._h)
+        return ms.value, n.value
+
+    def debug_cast_rays(self, ox, oy, angle_rad):
+        ox, oy, ang = [np.ascontiguousarray(a, dtype=np.float32) for a in (ox, oy, angle_rad)]
+        out = np.zeros(ox.size, dtype=np.float32)
+        capi.check(self._L.okenv_debug_cast_rays(self._h, capi.ptr(ox), capi.ptr(oy), capi.ptr(ang), ox.size, capi.ptr(out)),
+                   self._h)
+        return out
+
+
+def debug_sincos(x, device=0):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    s, c = np.zeros_like(x), np.zeros_like(x)
+    capi.check(capi.load().okenv_debug_sincos(int(device), capi.ptr(x), capi.ptr(s), capi.ptr(c), x.size))
+    return s, c

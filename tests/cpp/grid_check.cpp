@@ -1,0 +1,53 @@
+// grid_check.cpp -- host-side driver of the PRODUCT's traversal header (openkitchen_amd/csrc/ok_raycast.h,
+// ok_grid.h) for CPU tests: casts arbitrary rays through the uniform grid and reports first-hit t plus
+// work counters, so tests/test_grid_traversal.py can compare against the oracle's brute-force sweep for
+// millions of rays without a GPU.  Test infrastructure: built by the test into tests/cpp/_build/.
+#include <cstdint>
+#include <vector>
+
+#include "../../openkitchen_amd/csrc/ok_grid.h"
+
+extern "C"
+{
+    // returns 0, fills out_t[n]; tests/cells may be null
+    __attribute__((visibility("default"))) int gridcheck_cast(const float *segs_xyxy,
+                                                              int          S,
+                                                              float        cell,
+                                                              const float *ox,
+                                                              const float *oy,
+                                                              const float *angle_rad,
+                                                              int          n,
+                                                              float       *out_t,
+                                                              uint32_t    *out_tests,
+                                                              uint32_t    *out_cells,
+                                                              int32_t     *info /* nx, ny, nref, max_count, image bytes */)
+    {
+        const OkSeg *segs = reinterpret_cast<const OkSeg *>(segs_xyxy);
+        OkGridHost   gh   = okBuildGrid(segs, static_cast<size_t>(S), cell);
+        OkGridView32 v{};
+        v.g     = gh.g;
+        v.segs  = segs;
+        v.refs  = gh.refs.data();
+        v.start = gh.start.data();
+        if (info)
+        {
+            info[0] = gh.g.nx;
+            info[1] = gh.g.ny;
+            info[2] = static_cast<int32_t>(gh.refs.size());
+            info[3] = static_cast<int32_t>(gh.max_count);
+            info[4] = static_cast<int32_t>(gh.imageBytes16(S));
+        }
+        for (int i = 0; i < n; ++i)
+        {
+            float s, c;
+            ok_sincosf(angle_rad[i], &s, &c);
+            uint32_t tests = 0, cells = 0;
+            out_t[i]       = ok_cast_ray_grid<true>(v, ox[i], oy[i], c, s, &tests, &cells);
+            if (out_tests)
+                out_tests[i] = tests;
+            if (out_cells)
+                out_cells[i] = cells;
+        }
+        return 0;
+    }
+}
