@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the batched Environment step on MI355X.
+
+Metric (BASELINE.json): agent-steps/sec for config C2 = 4096 agents x 64 rays on Silverstone.csv with random
+actions (SURVEY.md section 8d recipe: VELOCITY mode, throttle~U[0,100), steer~U[-5,5) from Philox4x32 keyed
+(seed 1234, agent, step); crashed agents are re-placed on a Philox-chosen centre-line point at the start of the
+next step).  A "step" is one Environment::step() over the whole population.  State is resident in HBM before
+the timed region starts; nothing crosses PCIe inside it.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: one process per GPU; every rank owns its own shard of `--agents` agents (weak scaling: the global
+population is N x 4096, agent ids are global so the Philox streams do not repeat across ranks).  Agents never
+interact, so there is NO data-path collective; torch.distributed (RCCL) is used for the barriers around the
+timed region and for the max-over-ranks of the elapsed time.
+
+The single JSON line printed by rank 0 carries, besides the contract's keys:
+  roofline     -- HBM roofline of the step kernel from ALGORITHMIC bytes (354 B per agent-step for C2,
+                  SURVEY.md section 8d) divided by the kernel's average duration measured with HIP events on
+                  the stream the kernel runs on.  The path is VALU/LDS-bound, not HBM-bound (BASELINE.md
+                  section 5), so this fraction is small by construction; `traffic` is filled from the PMC
+                  profile under profiles/ when available.
+  cpu_baseline -- the CPU oracle (a port of the reference algorithm: brute-force sweep, `-O2
+                  -ffp-contract=off`) timed on this host, single thread, on a bounded sample of the same
+                  workload; `cpu_baseline_allcores` the same over all host cores; `cpu_c1` BASELINE config 1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+
+
+def algorithmic_bytes_per_agent_step(N, R, S):
+    """read 44 B + write 36 B of agent state, 4*R B of observation (distances), and the
+    shared segment array amortised over the population (16*S/N)."""
+    return 44.0 + 36.0 + 4.0 * R + 16.0 * S / N
+
+
+def cpu_baseline(track_name, R, seed, log):
+    """Times the oracle on this host.  Only rank 0 at N=1 calls this; ~10-30 s of CPU work in total."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    O.build_oracle(with_ref=False)
+    tr = O.Track(track_name)
+    fan = O.default_ray_fan(R)
+    out = {}
+
+    def run(N, steps, threads, track=tr, rays=fan):
+        env = O.OracleEnv(track.segments, N, rays.size, rays, (track.x, track.y, track.heading))
+        env.init_bench_state(0, 0)
+        env.rollout_random(5, seed, 0, 0, threads=threads)  # touch memory, leave the start line
+        t0 = time.perf_counter()
+        env.rollout_random(steps, seed, 0, 5, threads=threads)
+        dt = time.perf_counter() - t0
+        return N * steps / dt, dt
+
+    v, dt = run(128, 60, 1)
+    log("cpu oracle, 1 thread, 128 agents x %d rays x 60 steps on %s: %.3e agent-steps/s (%.1f s)" % (R, track_name, v, dt))
+    out["cpu_baseline"] = {"value": v, "unit": "agent-steps/s", "cores": 1, "kind": "port",
+                           "sample": "128 agents x %d rays x 60 steps of the same recipe on %s, brute-force sweep over all %d segments"
+                                     % (R, track_name, tr.S)}
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    v, dt = run(8 * threads, 60, threads)
+    log("cpu oracle, %d threads: %.3e agent-steps/s (%.1f s)" % (threads, v, dt))
+    out["cpu_baseline_allcores"] = {"value": v, "unit": "agent-steps/s", "cores": threads, "kind": "port",
+                                    "sample": "%d agents x %d rays x 60 steps, agents partitioned over %d threads" % (8 * threads, R, threads)}
+    tr1 = O.Track("Austin")
+    fan1 = O.default_ray_fan(16)
+    v, dt = run(64, 400, 1, tr1, fan1)
+    log("cpu oracle, BASELINE config 1 (64 x 16, Austin, 1 thread): %.3e agent-steps/s (%.1f s)" % (v, dt))
+    out["cpu_c1"] = {"value": v, "unit": "agent-steps/s", "cores": 1, "kind": "port",
+                     "sample": "BASELINE config 1: 64 agents x 16 rays, Austin, 400 steps"}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--agents", type=int, default=4096, help="agents per GPU (C2: 4096)")
+    ap.add_argument("--rays", type=int, default=64)
+    ap.add_argument("--track", default="Silverstone")
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--steps-per-launch", type=int, default=100,
+                    help="Environment steps advanced by one kernel launch (the action source is on the device)")
+    ap.add_argument("--grid-cell", type=float, default=0.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the Environment step has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def log(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    import openkitchen_amd as ok
+
+    ok.build()
+    track = ok.Track(args.track)
+    N, R = args.agents, args.rays
+    env = ok.BatchedEnvironment.from_track(track, N, R, device=local_rank, grid_cell=args.grid_cell)
+    info = env.info()
+    log("env: %s" % info)
+    agent_base = rank * N
+    env.init_bench_state(agent_base, ok.capi.MODE_VELOCITY)
+    spl = max(1, min(args.steps_per_launch, args.steps))
+
+    def run_steps(n, step0):
+        done = 0
+        while done < n:
+            c = min(spl, n - done)
+            env.rollout_random(c, args.seed, agent_base, step0 + done)
+            done += c
+
+    def fence():
+        env.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    # ---- warm-up (untimed) ----
+    run_steps(args.warmup, 0)
+    fence()
+    # ---- timed region: exactly K steps ----
+    env.set_timing(True)
+    t0 = time.perf_counter()
+    run_steps(args.steps, args.warmup)
+    env.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+    kernel_ms, launches = env.get_timing()
+    env.set_timing(False)
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed_max = float(el.item())
+
+    # ---- secondary figure: one launch per step (what a host-side policy between steps would see) ----
+    one_steps = min(args.steps, 500)
+    env.sync()
+    t1 = time.perf_counter()
+    for s in range(one_steps):
+        env.rollout_random(1, args.seed, agent_base, args.warmup + args.steps + s)
+    env.sync()
+    one_elapsed = time.perf_counter() - t1
+
+    state = env.snapshot()
+    crashed_frac = float(state["crashed"].mean())
+
+    if rank == 0:
+        total_agents = N * world
+        value = total_agents * args.steps / elapsed_max
+        b_alg = algorithmic_bytes_per_agent_step(N, R, track.S)
+        avg_launch_s = (kernel_ms * 1e-3) / max(launches, 1)
+        steps_per_launch_avg = args.steps / max(launches, 1)
+        bytes_per_launch = b_alg * N * steps_per_launch_avg
+        achieved_gbs = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        result = {
+            "metric": "agent-steps/sec",
+            "value": value,
+            "unit": "agent-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "C2: %d agents x %d rays per GPU, %s.csv (S=%d segments), Philox random actions + auto reset, "
+                                   "HIP fused kinematics+raycast+collision" % (N, R, args.track, track.S),
+                       "agents_per_gpu": N, "rays": R, "track": args.track, "segments": track.S,
+                       "global_agents": total_agents, "steps_per_launch": spl, "parallelism": "dp%d (agent shards, no collective)" % world,
+                       "grid_cell": info["grid_cell"], "lds_bytes": info["lds_bytes"]},
+            "rays_per_sec": value * R,
+            "value_one_launch_per_step": N * one_steps / one_elapsed,
+            "crashed_fraction_at_end": crashed_frac,
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "okStepKernel", "algorithmic_bytes_per_agent_step": b_alg,
+                         "avg_launch_ms": avg_launch_s * 1e3, "launches": int(launches),
+                         "kernel_only_agent_steps_per_sec": N * args.steps / (kernel_ms * 1e-3) if kernel_ms > 0 else None,
+                         "note": "VALU/LDS-bound path: algorithmic HBM traffic is ~0.35 KB per agent-step (BASELINE.md section 5)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result.update(cpu_baseline(args.track, R, args.seed, log))
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    env.close()
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

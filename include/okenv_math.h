@@ -53,12 +53,17 @@
 /*
  * sin and cos of an fp32 angle [rad], each correctly rounded from an fp64 evaluation whose error is
  * < 1e-15 for |x| < 1.6e6 rad (9e7 degrees; rot_ is never wrapped, Environment/Agent.cpp:86,112, so
- * large arguments do occur).  Beyond that the reduction loses accuracy gracefully but stays
- * deterministic and identical on both sides; NaN/Inf give NaN.
+ * large arguments do occur).  Beyond that the reduction loses accuracy gracefully (absolute angle error
+ * ~|x| * 1e-16) but stays deterministic and identical on both sides; NaN/Inf give NaN.
  */
 OK_HD void ok_sincosf(float x, float *s_out, float *c_out)
 {
-    const double xd = (double)x;
+    double xd = (double)x;
+    /* Absurdly large angles (|x| >= 2^31 rad ~ 1.2e11 degrees; fp32 spacing there is >= 256 rad, so the angle
+     * carries no information): fold with an exact fmod first so that the result stays in [-1,1] instead of
+     * overflowing.  fmod is exact by definition, hence still identical on CPU and GPU. */
+    if (!(__builtin_fabs(xd) < 2147483648.0))
+        xd = __builtin_fmod(xd, 6.283185307179586476925286766559);
     /* q = nearest integer to x * 2/pi */
     const double q = OK_RINT(xd * 0.63661977236758138243);
     /* pi/2 split in three parts; the first two carry 33 significant bits each, so q*P1 and q*P2 are

@@ -6,7 +6,7 @@ host side: it builds and loads that library and exposes typed wrappers.  Nothing
 in its place.
 """
 from . import _capi as capi  # noqa: F401
-from .build import build  # noqa: F401
+from .buildlib import build  # noqa: F401
 from .env import BatchedEnvironment, Track, debug_sincos, default_ray_fan, track_path  # noqa: F401
 
 __all__ = ["BatchedEnvironment", "Track", "build", "capi", "debug_sincos", "default_ray_fan", "track_path"]

@@ -1,4 +1,4 @@
-"""ctypes binding of the C ABI in include/okenv.h (libokenv.so, built by openkitchen_amd/build.py).
+"""ctypes binding of the C ABI in include/okenv.h (libokenv.so, built by openkitchen_amd/buildlib.py).
 
 Fails loudly if the shared object is missing or cannot be loaded: there is no Python or CPU fallback for
 the hot path.
@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from . import build as _build
+from . import buildlib as _build
 
 OKENV_OK = 0
 ERR_NAMES = {0: "OK", -1: "INVALID", -2: "HIP", -3: "NO_DEVICE", -4: "IO", -5: "STATE"}
@@ -63,7 +63,7 @@ def load(build_if_missing=True):
     path = lib_path()
     if not os.path.exists(path):
         if not build_if_missing:
-            raise OkenvError(-3, "libokenv.so is missing at %s (run python -m openkitchen_amd.build)" % path)
+            raise OkenvError(-3, "libokenv.so is missing at %s (run python -m openkitchen_amd.buildlib)" % path)
         _build.build()
     # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and opens it by path, so
     # if libokenv.so pulled in /opt/rocm's copy first the process would hold two runtimes and whichever

@@ -1,0 +1,75 @@
+"""ok_sincosf (include/okenv_math.h): faithful to glibc sinf/cosf (what the reference's host code calls) and to
+an fp64 reference; Philox known-answer test."""
+import ctypes as C
+
+import numpy as np
+
+import _oracle as O
+
+
+def ulp_diff(a, b):
+    ia = a.view(np.int32).astype(np.int64)
+    ib = b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
+    ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+    return np.abs(ia - ib)
+
+
+def test_sincos_against_fp64_and_glibc(oracle):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-10, 10, 300000), rng.uniform(-2e4, 2e4, 300000), rng.uniform(-1.5e6, 1.5e6, 100000),
+                        np.deg2rad(np.arange(-3600, 3601, 1, dtype=np.float64))]).astype(np.float32)
+    s, c = np.zeros_like(x), np.zeros_like(x)
+    O.lib().oracle_sincosf(x, s, c, x.size)
+    sr = np.sin(x.astype(np.float64)).astype(np.float32)
+    cr = np.cos(x.astype(np.float64)).astype(np.float32)
+    # correctly rounded on this sample (the fp64 evaluation error is ~1e-16)
+    assert ulp_diff(s, sr).max() <= 1 and (s != sr).mean() < 1e-5
+    assert ulp_diff(c, cr).max() <= 1 and (c != cr).mean() < 1e-5
+    libm = C.CDLL("libm.so.6")
+    libm.sinf.restype = libm.cosf.restype = C.c_float
+    libm.sinf.argtypes = libm.cosf.argtypes = [C.c_float]
+    sub = x[::40]
+    sg = np.array([libm.sinf(float(v)) for v in sub], dtype=np.float32)
+    cg = np.array([libm.cosf(float(v)) for v in sub], dtype=np.float32)
+    assert ulp_diff(s[::40], sg).max() <= 1
+    assert ulp_diff(c[::40], cg).max() <= 1
+    assert np.abs(s[::40].astype(np.float64) - sg).max() < 1e-7
+
+
+def test_sincos_special_values(oracle):
+    x = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 3.0e38], dtype=np.float32)
+    s, c = np.zeros_like(x), np.zeros_like(x)
+    O.lib().oracle_sincosf(x, s, c, x.size)
+    assert s[0] == 0 and c[0] == 1 and s[1] == 0 and c[1] == 1
+    assert np.isnan(s[2:5]).all() and np.isnan(c[2:5]).all()
+    assert s[5] == x[5] and c[5] == 1
+    assert abs(s[6]) <= 1 and abs(c[6]) <= 1
+
+
+def philox_ref(c, k):
+    """Independent pure-Python Philox4x32-10 (Salmon et al. 2011)."""
+    c = list(c)
+    k = list(k)
+    for _ in range(10):
+        p0 = 0xD2511F53 * c[0]
+        p1 = 0xCD9E8D57 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k[0]) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k[1]) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
+        k = [(k[0] + 0x9E3779B9) & 0xFFFFFFFF, (k[1] + 0xBB67AE85) & 0xFFFFFFFF]
+    return c
+
+
+def test_philox_known_answers(oracle):
+    # Random123 known-answer vectors for philox4x32-10
+    assert philox_ref([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert philox_ref([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert philox_ref([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    thr, steer, word = C.c_float(), C.c_float(), C.c_uint32()
+    for seed, agent, step in [(1234, 0, 0), (1234, 4095, 1999), (7, 123456, 99), (0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF)]:
+        O.lib().oracle_philox(seed, agent, step, C.byref(thr), C.byref(steer), C.byref(word))
+        r = philox_ref([agent, step, 0, 0], [seed, 0x6F6B656E])
+        t = np.float32(r[0] >> 8) * np.float32(2.0 ** -24) * np.float32(100.0)
+        st = np.float32(r[1] >> 8) * np.float32(2.0 ** -24) * np.float32(10.0) - np.float32(5.0)
+        assert np.float32(thr.value) == t and np.float32(steer.value) == st and word.value == r[2]
+        assert 0.0 <= thr.value < 100.0 and -5.0 <= steer.value < 5.0
