@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 #include "ok_raycast.h"
@@ -27,19 +28,9 @@ struct OkGridHost
     {
         return static_cast<size_t>(g.nx) * static_cast<size_t>(g.ny);
     }
-    // compact (16-bit) form usable?
-    bool fits16(const size_t num_segments) const
-    {
-        return num_segments <= 65535U && refs.size() <= 65535U && max_count <= 65535U;
-    }
-    // bytes of the LDS image: segments (16 B) | hdr (4 B per cell) | refs (2 B each), each part 16-B aligned
     static size_t align16(const size_t v)
     {
         return (v + 15U) & ~static_cast<size_t>(15U);
-    }
-    size_t imageBytes16(const size_t num_segments) const
-    {
-        return align16(num_segments * 16U) + align16(numCells() * 4U) + align16(refs.size() * 2U);
     }
 };
 
@@ -200,23 +191,120 @@ inline OkGridHost okBuildGrid(const OkSeg *segs, const size_t num_segments, floa
     return out;
 }
 
-// Picks the cell edge: `requested` if > 0, else the default; enlarged until the compact LDS image fits
-// `lds_budget` bytes (if it ever does).  Returns the grid; `*fits_lds` tells whether the compact form fits.
-inline OkGridHost
-okBuildGridAuto(const OkSeg *segs, const size_t num_segments, const float requested, const size_t lds_budget, bool *fits_lds)
+// The compact "poly" image staged into LDS (layout: points | hdr | runs, each part 16-byte aligned).
+struct OkPolyImage
+{
+    bool                 ok{false};     // encodable (index/count fields wide enough)
+    uint32_t             num_points{0}; // S + number of chains
+    uint32_t             num_runs{0};
+    std::vector<uint8_t> bytes;
+    size_t               off_hdr{0}, off_runs{0};
+    float                side_tol{0.F};
+    float                max_seg_len{0.F};
+};
+
+// Chains consecutive segments that share an end point bit for bit, turns every cell's ascending segment
+// list into runs of consecutive chained segments, and lays the result out for LDS.
+inline OkPolyImage okBuildPolyImage(const OkSeg *segs, const size_t num_segments, const OkGridHost &grid)
+{
+    OkPolyImage img;
+    // ---- point index of every segment ------------------------------------------------------------
+    std::vector<uint32_t> pidx(num_segments);
+    std::vector<uint8_t>  chained(num_segments, 0); // chained[i]: segment i continues segment i-1
+    uint32_t              chains = 0;
+    auto sameBits = [](const float a, const float b) {
+        uint32_t ua, ub;
+        std::memcpy(&ua, &a, 4);
+        std::memcpy(&ub, &b, 4);
+        return ua == ub;
+    };
+    double max_len = 0.0;
+    for (size_t i = 0; i < num_segments; ++i)
+    {
+        const bool cont = i > 0 && sameBits(segs[i].x1, segs[i - 1].x2) && sameBits(segs[i].y1, segs[i - 1].y2);
+        if (!cont)
+            ++chains;
+        chained[i] = cont ? 1 : 0;
+        pidx[i]    = static_cast<uint32_t>(i) + (chains - 1);
+        if (okgrid::finiteSeg(segs[i]))
+            max_len = std::fmax(max_len, std::hypot(static_cast<double>(segs[i].x2) - segs[i].x1,
+                                                    static_cast<double>(segs[i].y2) - segs[i].y1));
+    }
+    img.num_points  = static_cast<uint32_t>(num_segments) + chains;
+    img.max_seg_len = static_cast<float>(max_len);
+    std::vector<OkPoint> pts(img.num_points);
+    for (size_t i = 0; i < num_segments; ++i)
+    {
+        pts[pidx[i]]     = {segs[i].x1, segs[i].y1};
+        pts[pidx[i] + 1] = {segs[i].x2, segs[i].y2};
+    }
+    // ---- runs per cell ---------------------------------------------------------------------------
+    const size_t          ncell = grid.numCells();
+    std::vector<uint32_t> hdr(ncell, 0U), runs;
+    bool                  encodable = img.num_points <= OKPOLY_IDX_MASK;
+    const uint32_t        max_field = (1U << (32 - OKPOLY_IDX_BITS)) - 1U;
+    for (size_t c = 0; c < ncell && encodable; ++c)
+    {
+        const uint32_t first_run = static_cast<uint32_t>(runs.size());
+        uint32_t       k         = grid.start[c];
+        const uint32_t k_end     = grid.start[c + 1];
+        while (k < k_end)
+        {
+            const uint32_t seg0 = grid.refs[k];
+            uint32_t       n    = 1;
+            while (k + n < k_end && grid.refs[k + n] == seg0 + n && chained[seg0 + n] && n < max_field)
+                ++n;
+            runs.push_back(pidx[seg0] | (n << OKPOLY_IDX_BITS));
+            k += n;
+        }
+        const uint32_t count = static_cast<uint32_t>(runs.size()) - first_run;
+        if (count > max_field || first_run > OKPOLY_IDX_MASK)
+            encodable = false;
+        hdr[c] = first_run | (count << OKPOLY_IDX_BITS);
+    }
+    img.ok       = encodable;
+    img.num_runs = static_cast<uint32_t>(runs.size());
+    if (!encodable)
+        return img;
+    const size_t pts_b = OkGridHost::align16(pts.size() * sizeof(OkPoint));
+    const size_t hdr_b = OkGridHost::align16(hdr.size() * 4U);
+    const size_t run_b = OkGridHost::align16(runs.size() * 4U);
+    img.off_hdr        = pts_b;
+    img.off_runs       = pts_b + hdr_b;
+    img.bytes.assign(pts_b + hdr_b + run_b, 0);
+    std::memcpy(img.bytes.data(), pts.data(), pts.size() * sizeof(OkPoint));
+    std::memcpy(img.bytes.data() + img.off_hdr, hdr.data(), hdr.size() * 4U);
+    std::memcpy(img.bytes.data() + img.off_runs, runs.data(), runs.size() * 4U);
+    // side tolerance (ok_raycast.h): any point met by a walk lies within A = range + two cell diagonals + the
+    // longest segment + margin of the ray origin; rounding differences between the skip rule's sides and the
+    // reference's num_s / denom are below ~4 * 2^-23 * 4A; take 2^-17 * A (16x that).
+    const double A = 200.0 + 2.0 * 1.4143 * grid.g.cell + max_len + 2.0 * grid.margin;
+    img.side_tol   = static_cast<float>(std::ldexp(A, -17));
+    return img;
+}
+
+// Picks the cell edge: `requested` if > 0, else the default; enlarged until the compact image fits
+// `lds_budget` bytes (if it ever does).  `*fits_lds` tells whether `*image` is usable.
+inline OkGridHost okBuildGridAuto(const OkSeg *segs,
+                                  const size_t num_segments,
+                                  const float  requested,
+                                  const size_t lds_budget,
+                                  bool        *fits_lds,
+                                  OkPolyImage *image)
 {
     float      cell = requested > 0.F ? requested : 16.F;
     OkGridHost g;
     for (int attempt = 0; attempt < 24; ++attempt)
     {
-        g = okBuildGrid(segs, num_segments, cell);
-        if (g.fits16(num_segments) && g.imageBytes16(num_segments) <= lds_budget)
+        g      = okBuildGrid(segs, num_segments, cell);
+        *image = okBuildPolyImage(segs, num_segments, g);
+        if (image->ok && image->bytes.size() <= lds_budget)
         {
             *fits_lds = true;
             return g;
         }
-        if (num_segments * 16U + 64U > lds_budget || num_segments > 65535U)
-            break; // the segments alone do not fit: no cell size will help
+        if (num_segments * 8U + 64U > lds_budget)
+            break; // the points alone do not fit: no cell size will help
         cell *= 1.25F;
     }
     *fits_lds = false;

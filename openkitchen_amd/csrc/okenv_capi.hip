@@ -39,7 +39,8 @@ struct okenv
     uint32_t    flags{0};
     int         grid_mode{kGridLds};
     OkGridHost  grid;
-    size_t      image_bytes{0}, off_hdr{0}, off_refs{0};
+    OkPolyImage poly;
+    size_t      image_bytes{0};
     void       *d_image{nullptr};
     OkSeg      *d_segs{nullptr};
     uint32_t   *d_refs32{nullptr}, *d_start{nullptr};
@@ -147,8 +148,9 @@ OkStepParams baseParams(okenv *h)
     p.sensor_offset = h->sensor_offset;
     p.image         = static_cast<const uint8_t *>(h->d_image);
     p.image_bytes   = static_cast<uint32_t>(h->image_bytes);
-    p.off_hdr       = static_cast<uint32_t>(h->off_hdr);
-    p.off_refs      = static_cast<uint32_t>(h->off_refs);
+    p.off_hdr       = static_cast<uint32_t>(h->poly.off_hdr);
+    p.off_runs      = static_cast<uint32_t>(h->poly.off_runs);
+    p.side_tol      = h->poly.side_tol;
     p.geom          = h->grid.g;
     p.g_segs        = h->d_segs;
     p.g_refs32      = h->d_refs32;
@@ -267,12 +269,18 @@ extern "C"
 
         // lanes per agent
         h->G             = pow2ceil(num_rays) > 64 ? 64 : pow2ceil(num_rays);
+        if (const char *env_g = std::getenv("OKENV_LANES_PER_AGENT"))
+        { // tuning knob: fold the fan over fewer lanes (ray r, r+G, r+2G, ... share a lane)
+            const int g = std::atoi(env_g);
+            if (g >= 1 && g <= 64 && (g & (g - 1)) == 0 && g <= h->G)
+                h->G = g;
+        }
         h->rays_per_lane = (num_rays + h->G - 1) / h->G;
 
         // ---- grid ------------------------------------------------------------------------------------
         const OkSeg *segs = reinterpret_cast<const OkSeg *>(segments_xyxy);
         bool         fits = false;
-        h->grid           = okBuildGridAuto(segs, static_cast<size_t>(num_segments), grid_cell, kLdsBudget, &fits);
+        h->grid           = okBuildGridAuto(segs, static_cast<size_t>(num_segments), grid_cell, kLdsBudget, &fits, &h->poly);
         if (flags & OKENV_FLAG_BRUTE_FORCE)
             h->grid_mode = kGridBrute;
         else if (!fits || (flags & OKENV_FLAG_FORCE_GLOBAL_GRID))
@@ -286,26 +294,14 @@ extern "C"
         OK_HIP(nullptr, hipMemcpyAsync(h->d_segs, segs, sizeof(OkSeg) * num_segments, hipMemcpyHostToDevice, h->stream));
         if (h->grid_mode == kGridLds)
         {
-            const size_t seg_b = OkGridHost::align16(static_cast<size_t>(num_segments) * 16U);
-            const size_t hdr_b = OkGridHost::align16(h->grid.numCells() * 4U);
-            const size_t ref_b = OkGridHost::align16(h->grid.refs.size() * 2U);
-            h->off_hdr         = seg_b;
-            h->off_refs        = seg_b + hdr_b;
-            h->image_bytes     = seg_b + hdr_b + ref_b;
-            std::vector<uint8_t> img(h->image_bytes, 0);
-            std::memcpy(img.data(), segs, static_cast<size_t>(num_segments) * 16U);
-            uint32_t *hdr = reinterpret_cast<uint32_t *>(img.data() + h->off_hdr);
-            for (size_t c = 0; c < h->grid.numCells(); ++c)
-                hdr[c] = (h->grid.start[c] << 16) | (h->grid.start[c + 1] - h->grid.start[c]);
-            uint16_t *refs = reinterpret_cast<uint16_t *>(img.data() + h->off_refs);
-            for (size_t k = 0; k < h->grid.refs.size(); ++k)
-                refs[k] = static_cast<uint16_t>(h->grid.refs[k]);
+            h->image_bytes                  = h->poly.bytes.size();
+            const std::vector<uint8_t> &img = h->poly.bytes;
             uint8_t *dimg = nullptr;
             if ((rc = devAlloc(h, &dimg, h->image_bytes)) != OKENV_OK)
                 return fail(nullptr, rc, h->last_error);
             h->d_image = dimg;
             OK_HIP(nullptr, hipMemcpyAsync(dimg, img.data(), h->image_bytes, hipMemcpyHostToDevice, h->stream));
-            OK_HIP(nullptr, hipStreamSynchronize(h->stream)); // img goes out of scope
+            OK_HIP(nullptr, hipStreamSynchronize(h->stream));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepKernel<kGridLds>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->image_bytes)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okDebugCastKernel<kGridLds>),

@@ -15,10 +15,11 @@
 //     agent; R = 16: four agents per wave); fans wider than 64 rays loop inside the lane.  The per-agent
 //     min over rays of the squared hit distance -- the crash test -- is a xor-shuffle reduction inside
 //     those G lanes, no LDS, no atomics.
-//   * the track is staged ONCE per workgroup into LDS: Segment2d array + grid cell headers + cell
-//     reference lists (ok_grid.h), 90-125 KB for the config tracks, so one 1024-thread workgroup per CU;
-//     every ray-segment test then reads LDS, never HBM.  Adjacent rays of a fan start in the same cell and
-//     fan out slowly, so most LDS reads of a wave-instruction hit the same few addresses (broadcast).
+//   * the track is staged ONCE per workgroup into LDS as the compact "poly" image of ok_grid.h: boundary
+//     points (8 B each, shared by chained segments) + grid cell headers + per-cell runs of consecutive
+//     segments, 60-75 KB for the config tracks; every point evaluation and ray-segment test then reads LDS,
+//     never HBM.  Adjacent rays of a fan start in the same cell and fan out slowly, so most LDS reads of a
+//     wave-instruction hit the same few addresses (broadcast).
 //   * agent state is struct-of-arrays in HBM, read once at launch into registers, carried across the
 //     launch's steps, written back once; observations (sensor_hits_, their norms) and world hit points are
 //     written every step, agent-major/ray-minor, i.e. 256 contiguous bytes per wave-instruction at R = 64.
@@ -58,9 +59,10 @@ struct OkStepParams
     int           rays_per_lane;
     const float  *ray_deg;  // [R]
     float         sensor_offset;
-    // grid image in global memory: [segments | hdr | refs16], byte offsets from `image`
+    // compact image in global memory: [points | hdr | runs], byte offsets from `image` (ok_grid.h)
     const uint8_t *image;
-    uint32_t       image_bytes, off_hdr, off_refs;
+    uint32_t       image_bytes, off_hdr, off_runs;
+    float          side_tol;
     OkGridGeom     geom;
     // wide (global-memory) form
     const OkSeg    *g_segs;
@@ -97,7 +99,7 @@ __device__ __forceinline__ float okGroupMin(float v, const int G)
 
 template <int kMode>
 __device__ __forceinline__ float okCastRay(const OkStepParams &p,
-                                            const OkGridView16 &lds_view,
+                                            const OkPolyView   &lds_view,
                                             const float         ox,
                                             const float         oy,
                                             const float         rdx,
@@ -105,7 +107,7 @@ __device__ __forceinline__ float okCastRay(const OkStepParams &p,
 {
     if (kMode == kGridLds)
     {
-        return ok_cast_ray_grid<false>(lds_view, ox, oy, rdx, rdy, nullptr, nullptr);
+        return ok_cast_ray_poly<false>(lds_view, ox, oy, rdx, rdy, nullptr, nullptr, nullptr);
     }
     else if (kMode == kGridGlobal)
     {
@@ -145,14 +147,15 @@ template <int kMode>
 __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
-    OkGridView16 view{};
+    OkPolyView view{};
     if (kMode == kGridLds)
     {
         okStageImage(p, ok_lds);
-        view.g    = p.geom;
-        view.segs = reinterpret_cast<const OkSeg *>(ok_lds);
-        view.hdr  = reinterpret_cast<const uint32_t *>(ok_lds + p.off_hdr);
-        view.refs = reinterpret_cast<const uint16_t *>(ok_lds + p.off_refs);
+        view.g        = p.geom;
+        view.pts      = reinterpret_cast<const OkPoint *>(ok_lds);
+        view.hdr      = reinterpret_cast<const uint32_t *>(ok_lds + p.off_hdr);
+        view.runs     = reinterpret_cast<const uint32_t *>(ok_lds + p.off_runs);
+        view.side_tol = p.side_tol;
     }
 
     const int  G     = p.G;
@@ -424,14 +427,15 @@ __global__ void __launch_bounds__(1024)
 okDebugCastKernel(const OkStepParams p, const float *ox, const float *oy, const float *ang, int n, float *out_t)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
-    OkGridView16 view{};
+    OkPolyView view{};
     if (kMode == kGridLds)
     {
         okStageImage(p, ok_lds);
-        view.g    = p.geom;
-        view.segs = reinterpret_cast<const OkSeg *>(ok_lds);
-        view.hdr  = reinterpret_cast<const uint32_t *>(ok_lds + p.off_hdr);
-        view.refs = reinterpret_cast<const uint16_t *>(ok_lds + p.off_refs);
+        view.g        = p.geom;
+        view.pts      = reinterpret_cast<const OkPoint *>(ok_lds);
+        view.hdr      = reinterpret_cast<const uint32_t *>(ok_lds + p.off_hdr);
+        view.runs     = reinterpret_cast<const uint32_t *>(ok_lds + p.off_runs);
+        view.side_tol = p.side_tol;
     }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     {

@@ -20,7 +20,9 @@ extern "C"
                                                               float       *out_t,
                                                               uint32_t    *out_tests,
                                                               uint32_t    *out_cells,
-                                                              int32_t     *info /* nx, ny, nref, max_count, image bytes */)
+                                                              int32_t     *info /* nx, ny, nref, max_count, image bytes, runs, points */,
+                                                              int          form /* 0 wide (exact test on every registered segment), 1 compact poly */,
+                                                              uint32_t    *out_points)
     {
         const OkSeg *segs = reinterpret_cast<const OkSeg *>(segs_xyxy);
         OkGridHost   gh   = okBuildGrid(segs, static_cast<size_t>(S), cell);
@@ -29,24 +31,43 @@ extern "C"
         v.segs  = segs;
         v.refs  = gh.refs.data();
         v.start = gh.start.data();
+        OkPolyImage img = okBuildPolyImage(segs, static_cast<size_t>(S), gh);
+        OkPolyView  pv{};
+        if (form == 1)
+        {
+            if (!img.ok)
+                return -1;
+            pv.g        = gh.g;
+            pv.pts      = reinterpret_cast<const OkPoint *>(img.bytes.data());
+            pv.hdr      = reinterpret_cast<const uint32_t *>(img.bytes.data() + img.off_hdr);
+            pv.runs     = reinterpret_cast<const uint32_t *>(img.bytes.data() + img.off_runs);
+            pv.side_tol = img.side_tol;
+        }
         if (info)
         {
             info[0] = gh.g.nx;
             info[1] = gh.g.ny;
             info[2] = static_cast<int32_t>(gh.refs.size());
             info[3] = static_cast<int32_t>(gh.max_count);
-            info[4] = static_cast<int32_t>(gh.imageBytes16(S));
+            info[4] = static_cast<int32_t>(img.bytes.size());
+            info[5] = static_cast<int32_t>(img.num_runs);
+            info[6] = static_cast<int32_t>(img.num_points);
         }
         for (int i = 0; i < n; ++i)
         {
             float s, c;
             ok_sincosf(angle_rad[i], &s, &c);
-            uint32_t tests = 0, cells = 0;
-            out_t[i]       = ok_cast_ray_grid<true>(v, ox[i], oy[i], c, s, &tests, &cells);
+            uint32_t tests = 0, cells = 0, points = 0;
+            if (form == 1)
+                out_t[i] = ok_cast_ray_poly<true>(pv, ox[i], oy[i], c, s, &tests, &cells, &points);
+            else
+                out_t[i] = ok_cast_ray_grid<true>(v, ox[i], oy[i], c, s, &tests, &cells);
             if (out_tests)
                 out_tests[i] = tests;
             if (out_cells)
                 out_cells[i] = cells;
+            if (out_points)
+                out_points[i] = points;
         }
         return 0;
     }

@@ -21,7 +21,7 @@ def gridcheck():
     so = os.path.join(out_dir, "libgridcheck.so")
     subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src], check=True)
     G = C.CDLL(so)
-    G.gridcheck_cast.argtypes = [O.f32p, C.c_int, C.c_float, O.f32p, O.f32p, O.f32p, C.c_int, O.f32p, O.u32p, O.u32p, O.i32p]
+    G.gridcheck_cast.argtypes = [O.f32p, C.c_int, C.c_float, O.f32p, O.f32p, O.f32p, C.c_int, O.f32p, O.u32p, O.u32p, O.i32p, C.c_int, O.u32p]
     return G
 
 
@@ -48,20 +48,25 @@ def make_rays(t, n, seed):
     return ox, oy, ang
 
 
+@pytest.mark.parametrize("form", [0, 1])
 @pytest.mark.parametrize("name,cell", [("Silverstone", 16.0), ("Silverstone", 7.0), ("Spa", 16.0), ("Austin", 33.0), ("Monza", 300.0)])
-def test_grid_walk_equals_brute_force(oracle, gridcheck, name, cell):
+def test_grid_walk_equals_brute_force(oracle, gridcheck, name, cell, form):
     t = O.Track(name)
     ox, oy, ang = make_rays(t, 20000, 42)
     got = np.zeros(ox.size, dtype=np.float32)
     tests = np.zeros(ox.size, dtype=np.uint32)
     cells = np.zeros(ox.size, dtype=np.uint32)
-    info = np.zeros(5, dtype=np.int32)
+    points = np.zeros(ox.size, dtype=np.uint32)
+    info = np.zeros(8, dtype=np.int32)
     seg = np.ascontiguousarray(t.segments.reshape(-1))
-    assert gridcheck.gridcheck_cast(seg, t.S, cell, ox, oy, ang, ox.size, got, tests, cells, info) == 0
+    assert gridcheck.gridcheck_cast(seg, t.S, cell, ox, oy, ang, ox.size, got, tests, cells, info, form, points) == 0
     want = brute(t, ox, oy, ang)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert (want < 200).mean() > 0.4
     assert tests.mean() < 0.2 * t.S  # the walk really culls
+    if form == 1:
+        assert info[6] == t.S + 8  # 4 chained polylines + 4 closers
+        assert tests.mean() < 0.25 * points.mean() + 1  # the side rule skips most registered segments
     assert cells.max() <= info[0] + info[1] + 2
 
 
@@ -77,10 +82,11 @@ def test_degenerate_segment_sets(oracle, gridcheck):
         oy = rng.uniform(lo - 50, hi + 50, n).astype(np.float32)
         ang = rng.uniform(-np.pi, np.pi, n).astype(np.float32)
         got = np.zeros(n, dtype=np.float32)
-        info = np.zeros(5, dtype=np.int32)
+        info = np.zeros(8, dtype=np.int32)
         flat = np.ascontiguousarray(segs.reshape(-1))
-        tests, cells = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)
-        gridcheck.gridcheck_cast(flat, segs.shape[0], 16.0, ox, oy, ang, n, got, tests, cells, info)
+        tests, cells, points = (np.zeros(n, dtype=np.uint32) for _ in range(3))
         want = np.array([O.lib().oracle_cast_ray(float(ox[i]), float(oy[i]), float(ang[i]), flat, segs.shape[0]) for i in range(n)],
                         dtype=np.float32)
-        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        for form in (0, 1):
+            assert gridcheck.gridcheck_cast(flat, segs.shape[0], 16.0, ox, oy, ang, n, got, tests, cells, info, form, points) == 0
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), form
