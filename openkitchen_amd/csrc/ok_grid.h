@@ -191,90 +191,103 @@ inline OkGridHost okBuildGrid(const OkSeg *segs, const size_t num_segments, floa
     return out;
 }
 
-// The compact "poly" image staged into LDS (layout: points | hdr | runs, each part 16-byte aligned).
+// The compact "poly" image staged into LDS: a cell-major stream of boundary points.
+//   slots[]   8 B per point.  Each cell owns a contiguous, 16-byte aligned range of slots holding, run after run,
+//             the points of the chained segments registered in it (a run of n chained segments = n + 1 points),
+//             padded to an even count with a copy of its last point.
+//   hdr[cell] first_slot | (n_slots << 20)
+//   brk[]     one bit per slot: set when NO segment joins slot k-1 to slot k (first point of a run, padding).
+// Consecutive slots k, k+1 with brk(k+1) clear are one registered segment; because chained segments of the
+// reference's boundary polylines share end points bit for bit, a run costs one point per segment.
 struct OkPolyImage
 {
-    bool                 ok{false};     // encodable (index/count fields wide enough)
-    uint32_t             num_points{0}; // S + number of chains
+    bool                 ok{false}; // encodable (index/count fields wide enough)
+    uint32_t             num_slots{0};
     uint32_t             num_runs{0};
-    std::vector<uint8_t> bytes;
-    size_t               off_hdr{0}, off_runs{0};
+    std::vector<uint8_t> bytes;     // slots | hdr | brk, each part 16-byte aligned
+    size_t               off_hdr{0}, off_brk{0};
     float                side_tol{0.F};
     float                max_seg_len{0.F};
 };
 
-// Chains consecutive segments that share an end point bit for bit, turns every cell's ascending segment
-// list into runs of consecutive chained segments, and lays the result out for LDS.
 inline OkPolyImage okBuildPolyImage(const OkSeg *segs, const size_t num_segments, const OkGridHost &grid)
 {
     OkPolyImage img;
-    // ---- point index of every segment ------------------------------------------------------------
-    std::vector<uint32_t> pidx(num_segments);
-    std::vector<uint8_t>  chained(num_segments, 0); // chained[i]: segment i continues segment i-1
-    uint32_t              chains = 0;
     auto sameBits = [](const float a, const float b) {
         uint32_t ua, ub;
         std::memcpy(&ua, &a, 4);
         std::memcpy(&ub, &b, 4);
         return ua == ub;
     };
-    double max_len = 0.0;
+    // chained[i]: segment i starts where segment i-1 ends, bit for bit
+    std::vector<uint8_t> chained(num_segments, 0);
+    double               max_len = 0.0;
     for (size_t i = 0; i < num_segments; ++i)
     {
-        const bool cont = i > 0 && sameBits(segs[i].x1, segs[i - 1].x2) && sameBits(segs[i].y1, segs[i - 1].y2);
-        if (!cont)
-            ++chains;
-        chained[i] = cont ? 1 : 0;
-        pidx[i]    = static_cast<uint32_t>(i) + (chains - 1);
+        chained[i] = (i > 0 && sameBits(segs[i].x1, segs[i - 1].x2) && sameBits(segs[i].y1, segs[i - 1].y2)) ? 1 : 0;
         if (okgrid::finiteSeg(segs[i]))
             max_len = std::fmax(max_len, std::hypot(static_cast<double>(segs[i].x2) - segs[i].x1,
                                                     static_cast<double>(segs[i].y2) - segs[i].y1));
     }
-    img.num_points  = static_cast<uint32_t>(num_segments) + chains;
     img.max_seg_len = static_cast<float>(max_len);
-    std::vector<OkPoint> pts(img.num_points);
-    for (size_t i = 0; i < num_segments; ++i)
-    {
-        pts[pidx[i]]     = {segs[i].x1, segs[i].y1};
-        pts[pidx[i] + 1] = {segs[i].x2, segs[i].y2};
-    }
-    // ---- runs per cell ---------------------------------------------------------------------------
     const size_t          ncell = grid.numCells();
-    std::vector<uint32_t> hdr(ncell, 0U), runs;
-    bool                  encodable = img.num_points <= OKPOLY_IDX_MASK;
-    const uint32_t        max_field = (1U << (32 - OKPOLY_IDX_BITS)) - 1U;
-    for (size_t c = 0; c < ncell && encodable; ++c)
+    std::vector<OkPoint>  slots;
+    std::vector<uint8_t>  brk; // one byte per slot while building
+    std::vector<uint32_t> hdr(ncell, 0U);
+    const uint32_t        max_count = (1U << (32 - OKPOLY_IDX_BITS)) - 1U;
+    bool                  encodable = true;
+    for (size_t c = 0; c < ncell; ++c)
     {
-        const uint32_t first_run = static_cast<uint32_t>(runs.size());
-        uint32_t       k         = grid.start[c];
-        const uint32_t k_end     = grid.start[c + 1];
+        const uint32_t first = static_cast<uint32_t>(slots.size()); // always even
+        uint32_t       k     = grid.start[c];
+        const uint32_t k_end = grid.start[c + 1];
         while (k < k_end)
         {
             const uint32_t seg0 = grid.refs[k];
             uint32_t       n    = 1;
-            while (k + n < k_end && grid.refs[k + n] == seg0 + n && chained[seg0 + n] && n < max_field)
+            while (k + n < k_end && grid.refs[k + n] == seg0 + n && chained[seg0 + n])
                 ++n;
-            runs.push_back(pidx[seg0] | (n << OKPOLY_IDX_BITS));
+            slots.push_back({segs[seg0].x1, segs[seg0].y1});
+            brk.push_back(1);
+            for (uint32_t j = 0; j < n; ++j)
+            {
+                slots.push_back({segs[seg0 + j].x2, segs[seg0 + j].y2});
+                brk.push_back(0);
+            }
+            ++img.num_runs;
             k += n;
         }
-        const uint32_t count = static_cast<uint32_t>(runs.size()) - first_run;
-        if (count > max_field || first_run > OKPOLY_IDX_MASK)
+        if ((slots.size() - first) & 1U)
+        {
+            slots.push_back(slots.back());
+            brk.push_back(1);
+        }
+        const uint32_t count = static_cast<uint32_t>(slots.size()) - first;
+        if (count > max_count || first > OKPOLY_IDX_MASK)
             encodable = false;
-        hdr[c] = first_run | (count << OKPOLY_IDX_BITS);
+        hdr[c] = first | (count << OKPOLY_IDX_BITS);
     }
-    img.ok       = encodable;
-    img.num_runs = static_cast<uint32_t>(runs.size());
+    slots.push_back({0.F, 0.F}); // the exact test of slot k reads k+1; keep the last read in bounds
+    slots.push_back({0.F, 0.F});
+    brk.push_back(1);
+    brk.push_back(1);
+    img.ok        = encodable;
+    img.num_slots = static_cast<uint32_t>(slots.size());
     if (!encodable)
         return img;
-    const size_t pts_b = OkGridHost::align16(pts.size() * sizeof(OkPoint));
-    const size_t hdr_b = OkGridHost::align16(hdr.size() * 4U);
-    const size_t run_b = OkGridHost::align16(runs.size() * 4U);
-    img.off_hdr        = pts_b;
-    img.off_runs       = pts_b + hdr_b;
-    img.bytes.assign(pts_b + hdr_b + run_b, 0);
-    std::memcpy(img.bytes.data(), pts.data(), pts.size() * sizeof(OkPoint));
+    std::vector<uint32_t> brk_bits((slots.size() + 31U) / 32U, 0U);
+    for (size_t i = 0; i < brk.size(); ++i)
+        if (brk[i])
+            brk_bits[i >> 5] |= 1U << (i & 31U);
+    const size_t slot_b = OkGridHost::align16(slots.size() * sizeof(OkPoint));
+    const size_t hdr_b  = OkGridHost::align16(hdr.size() * 4U);
+    const size_t brk_b  = OkGridHost::align16(brk_bits.size() * 4U);
+    img.off_hdr         = slot_b;
+    img.off_brk         = slot_b + hdr_b;
+    img.bytes.assign(slot_b + hdr_b + brk_b, 0);
+    std::memcpy(img.bytes.data(), slots.data(), slots.size() * sizeof(OkPoint));
     std::memcpy(img.bytes.data() + img.off_hdr, hdr.data(), hdr.size() * 4U);
-    std::memcpy(img.bytes.data() + img.off_runs, runs.data(), runs.size() * 4U);
+    std::memcpy(img.bytes.data() + img.off_brk, brk_bits.data(), brk_bits.size() * 4U);
     // side tolerance (ok_raycast.h): any point met by a walk lies within A = range + two cell diagonals + the
     // longest segment + margin of the ray origin; rounding differences between the skip rule's sides and the
     // reference's num_s / denom are below ~4 * 2^-23 * 4A; take 2^-17 * A (16x that).

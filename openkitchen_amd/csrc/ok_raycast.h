@@ -82,21 +82,23 @@ struct OkGridView32
     }
 };
 
-// Compact "poly" view, staged into LDS by the step kernel.  Chained segments (seg[i].p2 == seg[i+1].p1 bit for
-// bit, as along the reference's four boundary polylines) share their end points:
-//   pts[]          8 B per point; segment i is (pts[pidx(i)], pts[pidx(i) + 1])
-//   hdr[cell]      first_run | (run_count << 20)
-//   runs[r]        first_point | (n_segments << 20): segments (first_point + j, first_point + j + 1), j < n
+// Compact "poly" view, staged into LDS by the step kernel (layout built by ok_grid.h: a cell-major stream of
+// boundary points, a 4-byte header per cell and one "no segment ends here" bit per slot).
 struct OkPolyView
 {
     OkGridGeom      g;
-    const OkPoint  *pts;
-    const uint32_t *hdr;
-    const uint32_t *runs;
+    const OkPoint  *slots;
+    const uint32_t *hdr; // first_slot | (n_slots << 20); n_slots is even, first_slot is even
+    const uint32_t *brk; // bit k set: slots k-1 and k are NOT joined by a segment
     float           side_tol;
 };
 #define OKPOLY_IDX_BITS 20
 #define OKPOLY_IDX_MASK 0xFFFFFU
+
+struct OkPointPair // two consecutive slots, 16 bytes: one ds_read_b128
+{
+    OkPoint a, b;
+};
 
 // Environment/CollisionChecker.cu:8-35, operation for operation.
 OKRC_HD bool ok_ray_segment(const float ox,
@@ -125,6 +127,15 @@ OKRC_HD bool ok_ray_segment(const float ox,
     return false;
 }
 
+OKRC_HD float okRcpApprox(const float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0F / x;
+#endif
+}
+
 // The cell walk shared by both forms: slab clip of [0, range] against the grid box, then DDA.
 struct OkWalk
 {
@@ -137,8 +148,10 @@ struct OkWalk
     {
         const bool  par_x  = __builtin_fabsf(rdx) < 1e-30F;
         const bool  par_y  = __builtin_fabsf(rdy) < 1e-30F;
-        const float inv_dx = par_x ? 0.0F : 1.0F / rdx;
-        const float inv_dy = par_y ? 0.0F : 1.0F / rdy;
+        // The walk only has to be conservative (the registration margin absorbs its rounding), so the device
+        // uses the 1-ulp hardware reciprocal instead of an IEEE division here.
+        const float inv_dx = par_x ? 0.0F : okRcpApprox(rdx);
+        const float inv_dy = par_y ? 0.0F : okRcpApprox(rdy);
         float       t_in   = 0.0F;
         t_out              = OK_SENSOR_RANGE;
         if (par_x)
@@ -252,15 +265,82 @@ OKRC_HD float ok_side(const OkPoint p, const float ox, const float oy, const flo
     return __builtin_fmaf(ax, rdy, -(ay * rdx));
 }
 
-// true when the segment whose end points have sides s0, s1 cannot be hit (see the header comment)
+// true when the segment whose end points have sides s0, s1 cannot be hit (see the header comment):
+// equal signs and both magnitudes above the tolerance.
 OKRC_HD bool ok_same_side(const float s0, const float s1, const float tol)
 {
-    const float lo = __builtin_fminf(s0, s1);
-    const float hi = __builtin_fmaxf(s0, s1);
-    return (lo > tol) || (hi < -tol);
+    return (s0 * s1 > 0.0F) && (__builtin_fminf(__builtin_fabsf(s0), __builtin_fabsf(s1)) > tol);
 }
 
-// Compact form.  `tests` counts exact tests, `cells` cells, `points` point evaluations (statistics only).
+#define OKPOLY_NONE 0xFFFFFFFFU
+
+// Compact form.
+//  * Per cell the lane streams its slots two at a time (one 16-byte LDS read), evaluates the side of each point
+//    and applies the skip rule to every consecutive pair.  The next cell's header is fetched before the current
+//    cell is processed, so the dependent LDS round trips per cell are header -> points, nothing else.
+//  * Segments that survive the side rule are not tested on the spot: their first slot index is parked in a
+//    two-entry per-lane stack and the exact tests run once per cell, after the point loop.  On the GPU this
+//    keeps the long, division-heavy exact test out of the divergent inner loop: a wave pays for it once or
+//    twice per cell instead of once per straggling lane.  The order of exact tests does not matter (min is
+//    order independent) and every parked segment is tested before the cell's termination check, so the
+//    result is unchanged.
+// `tests` counts exact tests, `cells` cells, `points` point evaluations (statistics only).
+// exact test of the registered segment (slot k, slot k+1); returns the updated first-hit parameter
+OKRC_HD float okExactSlot(const OkPolyView &v,
+                          const uint32_t    k,
+                          const float       ox,
+                          const float       oy,
+                          const float       rdx,
+                          const float       rdy,
+                          const float       min_t)
+{
+    const OkPoint a = v.slots[k];
+    const OkPoint b = v.slots[k + 1];
+    float         t;
+    return ok_ray_segment(ox, oy, rdx, rdy, a.x, a.y, b.x, b.y, min_t, t) ? t : min_t;
+}
+
+// Per-lane state of the compact walk that the park/flush steps update.  Passed and returned BY VALUE: with
+// reference parameters hipcc turned `if (empty0) pend0 = k; else pend1 = k;` into a store through a selected
+// pointer, which kept the two-entry stack in scratch memory instead of registers.
+struct OkPending
+{
+    uint32_t p0, p1; // first-slot indices of parked segments, OKPOLY_NONE when empty
+    float    min_t;
+};
+
+// Parks segment (k, k+1) unless slot k+1 starts a new run.
+template <bool kCount>
+OKRC_HD OkPending okPark(const OkPolyView &v,
+                         const uint32_t    k,
+                         OkPending         st,
+                         const float       ox,
+                         const float       oy,
+                         const float       rdx,
+                         const float       rdy,
+                         uint32_t         *tests)
+{
+    const uint32_t k1 = k + 1U;
+    if ((v.brk[k1 >> 5] >> (k1 & 31U)) & 1U)
+        return st;
+    const bool e0 = st.p0 == OKPOLY_NONE;
+    const bool e1 = st.p1 == OKPOLY_NONE;
+    if (!e0 && !e1)
+    { // three survivors in one cell: make room
+        if (kCount)
+            *tests += 1;
+        st.min_t = okExactSlot(v, st.p0, ox, oy, rdx, rdy, st.min_t);
+        st.p0    = st.p1;
+        st.p1    = k;
+    }
+    else
+    {
+        st.p1 = e0 ? st.p1 : k;
+        st.p0 = e0 ? k : st.p0;
+    }
+    return st;
+}
+
 template <bool kCount>
 OKRC_HD float ok_cast_ray_poly(const OkPolyView &v,
                                const float       ox,
@@ -271,49 +351,79 @@ OKRC_HD float ok_cast_ray_poly(const OkPolyView &v,
                                uint32_t         *cells,
                                uint32_t         *points)
 {
-    const OkGridGeom &g     = v.g;
-    float             min_t = OK_SENSOR_RANGE;
+    const OkGridGeom &g = v.g;
     OkWalk            w;
     if (!w.init(g, ox, oy, rdx, rdy))
-        return min_t;
+        return OK_SENSOR_RANGE;
     const float tol = v.side_tol;
-    for (int guard = g.nx + g.ny + 2; guard > 0; --guard)
+    OkPending   st{OKPOLY_NONE, OKPOLY_NONE, OK_SENSOR_RANGE};
+    uint32_t    h     = v.hdr[w.iy * g.nx + w.ix];
+    int         guard = g.nx + g.ny + 2; // the walk visits at most nx + ny cells: termination is unconditional
+    bool        done  = false;
+    while (!done)
     {
-        const uint32_t h     = v.hdr[w.iy * g.nx + w.ix];
-        uint32_t       r     = h & OKPOLY_IDX_MASK;
-        const uint32_t r_end = r + (h >> OKPOLY_IDX_BITS);
-        if (kCount)
-            *cells += 1;
-        for (; r < r_end; ++r)
+        // ---- phase A: walk cells and evaluate points until a segment survives the side rule -------------
+        // (On the GPU every lane of the wave leaves this loop before any lane enters phase B, so the costly
+        // exact tests below run once per "round" for all lanes that need them, not once per cell.)
+        while (true)
         {
-            const uint32_t run = v.runs[r];
-            uint32_t       p   = run & OKPOLY_IDX_MASK;
-            const uint32_t n   = run >> OKPOLY_IDX_BITS;
-            OkPoint        p0  = v.pts[p];
-            float          s0  = ok_side(p0, ox, oy, rdx, rdy);
+            // header of the cell the walk would enter next (clamped; unused if the walk ends first)
+            const bool go_x = w.tmax_x < w.tmax_y;
+            int        nx_i = w.ix + (go_x ? w.step_x : 0);
+            int        ny_i = w.iy + (go_x ? 0 : w.step_y);
+            nx_i            = nx_i < 0 ? 0 : (nx_i >= g.nx ? g.nx - 1 : nx_i);
+            ny_i            = ny_i < 0 ? 0 : (ny_i >= g.ny ? g.ny - 1 : ny_i);
+            const uint32_t h_next = v.hdr[ny_i * g.nx + nx_i];
+
+            uint32_t       k     = h & OKPOLY_IDX_MASK;
+            const uint32_t k_end = k + (h >> OKPOLY_IDX_BITS);
             if (kCount)
-                *points += n + 1;
-            for (uint32_t j = 0; j < n; ++j)
             {
-                ++p;
-                const OkPoint p1 = v.pts[p];
-                const float   s1 = ok_side(p1, ox, oy, rdx, rdy);
-                if (!ok_same_side(s0, s1, tol))
+                *cells += 1;
+                *points += (h >> OKPOLY_IDX_BITS);
+            }
+            float s_prev = 0.F;
+            bool  first  = true;
+            for (; k < k_end; k += 2)
+            {
+                const OkPointPair pp = *reinterpret_cast<const OkPointPair *>(&v.slots[k]);
+                const float       sa = ok_side(pp.a, ox, oy, rdx, rdy);
+                const float       sb = ok_side(pp.b, ox, oy, rdx, rdy);
+                s_prev               = first ? sa : s_prev; // the cell's first slot has no predecessor
+                first                = false;
+                const bool ka        = !ok_same_side(s_prev, sa, tol);
+                const bool kb        = !ok_same_side(sa, sb, tol);
+                if (ka | kb)
                 {
-                    if (kCount)
-                        *tests += 1;
-                    float t;
-                    if (ok_ray_segment(ox, oy, rdx, rdy, p0.x, p0.y, p1.x, p1.y, min_t, t))
-                        min_t = t;
+                    if (ka)
+                        st = okPark<kCount>(v, k - 1U, st, ox, oy, rdx, rdy, tests);
+                    if (kb)
+                        st = okPark<kCount>(v, k, st, ox, oy, rdx, rdy, tests);
                 }
-                p0 = p1;
-                s0 = s1;
+                s_prev = sb;
+            }
+            h = h_next;
+            if (st.p0 != OKPOLY_NONE)
+                break; // something to test exactly: leave the walk, stay in this cell
+            if (__builtin_fminf(st.min_t, w.t_out) <= w.exitT() || !w.advance(g) || --guard <= 0)
+            {
+                done = true;
+                break;
             }
         }
-        if (__builtin_fminf(min_t, w.t_out) <= w.exitT())
-            break;
-        if (!w.advance(g))
-            break;
+        // ---- phase B: exact tests of the parked segments, then this cell's termination check ---------------
+        if (!done)
+        {
+            if (kCount)
+                *tests += (st.p1 != OKPOLY_NONE) ? 2 : 1;
+            st.min_t = okExactSlot(v, st.p0, ox, oy, rdx, rdy, st.min_t);
+            if (st.p1 != OKPOLY_NONE)
+                st.min_t = okExactSlot(v, st.p1, ox, oy, rdx, rdy, st.min_t);
+            st.p0 = OKPOLY_NONE;
+            st.p1 = OKPOLY_NONE;
+            if (__builtin_fminf(st.min_t, w.t_out) <= w.exitT() || !w.advance(g) || --guard <= 0)
+                done = true;
+        }
     }
-    return min_t;
+    return st.min_t;
 }

@@ -15,9 +15,9 @@
 //     agent; R = 16: four agents per wave); fans wider than 64 rays loop inside the lane.  The per-agent
 //     min over rays of the squared hit distance -- the crash test -- is a xor-shuffle reduction inside
 //     those G lanes, no LDS, no atomics.
-//   * the track is staged ONCE per workgroup into LDS as the compact "poly" image of ok_grid.h: boundary
-//     points (8 B each, shared by chained segments) + grid cell headers + per-cell runs of consecutive
-//     segments, 60-75 KB for the config tracks; every point evaluation and ray-segment test then reads LDS,
+//   * the track is staged ONCE per workgroup into LDS as the compact "poly" image of ok_grid.h: a cell-major
+//     stream of boundary points (8 B each, shared by chained segments) + a 4-byte header per grid cell,
+//     90-115 KB for the config tracks; every point evaluation and ray-segment test then reads LDS,
 //     never HBM.  Adjacent rays of a fan start in the same cell and fan out slowly, so most LDS reads of a
 //     wave-instruction hit the same few addresses (broadcast).
 //   * agent state is struct-of-arrays in HBM, read once at launch into registers, carried across the
@@ -59,9 +59,9 @@ struct OkStepParams
     int           rays_per_lane;
     const float  *ray_deg;  // [R]
     float         sensor_offset;
-    // compact image in global memory: [points | hdr | runs], byte offsets from `image` (ok_grid.h)
+    // compact image in global memory: [slots | hdr | brk], byte offsets from `image` (ok_grid.h)
     const uint8_t *image;
-    uint32_t       image_bytes, off_hdr, off_runs;
+    uint32_t       image_bytes, off_hdr, off_brk;
     float          side_tol;
     OkGridGeom     geom;
     // wide (global-memory) form
@@ -107,7 +107,11 @@ __device__ __forceinline__ float okCastRay(const OkStepParams &p,
 {
     if (kMode == kGridLds)
     {
+#if defined(OKENV_ABLATE) && OKENV_ABLATE == 1
+        return OK_SENSOR_RANGE * (0.5F + 0.25F * rdx); // timing experiment only: no raycast at all
+#else
         return ok_cast_ray_poly<false>(lds_view, ox, oy, rdx, rdy, nullptr, nullptr, nullptr);
+#endif
     }
     else if (kMode == kGridGlobal)
     {
@@ -152,9 +156,9 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
     {
         okStageImage(p, ok_lds);
         view.g        = p.geom;
-        view.pts      = reinterpret_cast<const OkPoint *>(ok_lds);
+        view.slots    = reinterpret_cast<const OkPoint *>(ok_lds);
         view.hdr      = reinterpret_cast<const uint32_t *>(ok_lds + p.off_hdr);
-        view.runs     = reinterpret_cast<const uint32_t *>(ok_lds + p.off_runs);
+        view.brk      = reinterpret_cast<const uint32_t *>(ok_lds + p.off_brk);
         view.side_tol = p.side_tol;
     }
 
@@ -432,9 +436,9 @@ okDebugCastKernel(const OkStepParams p, const float *ox, const float *oy, const 
     {
         okStageImage(p, ok_lds);
         view.g        = p.geom;
-        view.pts      = reinterpret_cast<const OkPoint *>(ok_lds);
+        view.slots    = reinterpret_cast<const OkPoint *>(ok_lds);
         view.hdr      = reinterpret_cast<const uint32_t *>(ok_lds + p.off_hdr);
-        view.runs     = reinterpret_cast<const uint32_t *>(ok_lds + p.off_runs);
+        view.brk      = reinterpret_cast<const uint32_t *>(ok_lds + p.off_brk);
         view.side_tol = p.side_tol;
     }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)

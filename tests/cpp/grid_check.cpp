@@ -38,9 +38,9 @@ extern "C"
             if (!img.ok)
                 return -1;
             pv.g        = gh.g;
-            pv.pts      = reinterpret_cast<const OkPoint *>(img.bytes.data());
+            pv.slots    = reinterpret_cast<const OkPoint *>(img.bytes.data());
             pv.hdr      = reinterpret_cast<const uint32_t *>(img.bytes.data() + img.off_hdr);
-            pv.runs     = reinterpret_cast<const uint32_t *>(img.bytes.data() + img.off_runs);
+            pv.brk      = reinterpret_cast<const uint32_t *>(img.bytes.data() + img.off_brk);
             pv.side_tol = img.side_tol;
         }
         if (info)
@@ -51,7 +51,7 @@ extern "C"
             info[3] = static_cast<int32_t>(gh.max_count);
             info[4] = static_cast<int32_t>(img.bytes.size());
             info[5] = static_cast<int32_t>(img.num_runs);
-            info[6] = static_cast<int32_t>(img.num_points);
+            info[6] = static_cast<int32_t>(img.num_slots);
         }
         for (int i = 0; i < n; ++i)
         {
