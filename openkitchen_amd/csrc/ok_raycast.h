@@ -143,8 +143,9 @@ struct OkWalk
     float tmax_x, tmax_y, tdel_x, tdel_y;
     float t_out; // parameter at which the ray leaves the grid box or reaches the sensor range
 
-    // returns false if the ray misses the grid box altogether
-    OKRC_HD bool init(const OkGridGeom &g, const float ox, const float oy, const float rdx, const float rdy)
+    // Starts the walk at ray parameter max(t_start, entry into the grid box); returns false if [t_start, range]
+    // misses the grid box altogether.
+    OKRC_HD bool init(const OkGridGeom &g, const float ox, const float oy, const float rdx, const float rdy, const float t_start = 0.0F)
     {
         const bool  par_x  = __builtin_fabsf(rdx) < 1e-30F;
         const bool  par_y  = __builtin_fabsf(rdy) < 1e-30F;
@@ -152,7 +153,7 @@ struct OkWalk
         // uses the 1-ulp hardware reciprocal instead of an IEEE division here.
         const float inv_dx = par_x ? 0.0F : okRcpApprox(rdx);
         const float inv_dy = par_y ? 0.0F : okRcpApprox(rdy);
-        float       t_in   = 0.0F;
+        float       t_in   = t_start;
         t_out              = OK_SENSOR_RANGE;
         if (par_x)
         {
@@ -341,6 +342,99 @@ OKRC_HD OkPending okPark(const OkPolyView &v,
     return st;
 }
 
+// What a walk over part of a ray reports.
+struct OkIntervalResult
+{
+    float min_t;      // smallest valid t among the segments looked at (OK_SENSOR_RANGE if none)
+    float t_reached;  // the ray has been covered up to this parameter
+    bool  conclusive; // min_t is the ray's final first-hit value: a hit inside the covered part, or the walk reached
+                      // the sensor range / left the grid
+};
+
+// Walks the cells the ray crosses for parameters in [t_a, t_b] and reports the first hit among the segments
+// registered there.  The whole ray is the interval [0, +inf).  Splitting a ray into intervals and taking the min
+// of their min_t gives the same bits as one walk: every cell overlapping [t_a, t_b] is processed, a valid t found
+// in ANY cell is a valid t of the ray (the exact test does not depend on the cell it was found in), and a walk
+// only stops early on a hit that lies inside the part it has covered.
+template <bool kCount>
+OKRC_HD OkIntervalResult ok_cast_poly_interval(const OkPolyView &v,
+                                               const float       ox,
+                                               const float       oy,
+                                               const float       rdx,
+                                               const float       rdy,
+                                               const float       t_a,
+                                               const float       t_b,
+                                               uint32_t         *tests,
+                                               uint32_t         *cells,
+                                               uint32_t         *points)
+{
+    const OkGridGeom &g = v.g;
+    OkWalk            w;
+    if (!w.init(g, ox, oy, rdx, rdy, t_a))
+        return {OK_SENSOR_RANGE, OK_SENSOR_RANGE, true};
+    const float tol = v.side_tol;
+    OkPending   st{OKPOLY_NONE, OKPOLY_NONE, OK_SENSOR_RANGE};
+    uint32_t    h = v.hdr[w.iy * g.nx + w.ix];
+    // The walk visits at most nx + ny cells; the explicit bound makes termination unconditional.
+    for (int guard = g.nx + g.ny + 2; guard > 0; --guard)
+    {
+        // header of the cell the walk would enter next (clamped; unused if the walk ends first)
+        const bool go_x = w.tmax_x < w.tmax_y;
+        int        nx_i = w.ix + (go_x ? w.step_x : 0);
+        int        ny_i = w.iy + (go_x ? 0 : w.step_y);
+        nx_i            = nx_i < 0 ? 0 : (nx_i >= g.nx ? g.nx - 1 : nx_i);
+        ny_i            = ny_i < 0 ? 0 : (ny_i >= g.ny ? g.ny - 1 : ny_i);
+        const uint32_t h_next = v.hdr[ny_i * g.nx + nx_i];
+
+        uint32_t       k     = h & OKPOLY_IDX_MASK;
+        const uint32_t k_end = k + (h >> OKPOLY_IDX_BITS);
+        if (kCount)
+        {
+            *cells += 1;
+            *points += (h >> OKPOLY_IDX_BITS);
+        }
+        float s_prev = 0.F;
+        bool  first  = true;
+        for (; k < k_end; k += 2)
+        {
+            const OkPointPair pp = *reinterpret_cast<const OkPointPair *>(&v.slots[k]);
+            const float       sa = ok_side(pp.a, ox, oy, rdx, rdy);
+            const float       sb = ok_side(pp.b, ox, oy, rdx, rdy);
+            s_prev               = first ? sa : s_prev; // the cell's first slot has no predecessor
+            first                = false;
+            const bool ka        = !ok_same_side(s_prev, sa, tol);
+            const bool kb        = !ok_same_side(sa, sb, tol);
+            if (ka | kb)
+            {
+                if (ka)
+                    st = okPark<kCount>(v, k - 1U, st, ox, oy, rdx, rdy, tests);
+                if (kb)
+                    st = okPark<kCount>(v, k, st, ox, oy, rdx, rdy, tests);
+            }
+            s_prev = sb;
+        }
+        // exact tests of the segments parked in this cell
+        while (st.p0 != OKPOLY_NONE)
+        {
+            if (kCount)
+                *tests += 1;
+            st.min_t = okExactSlot(v, st.p0, ox, oy, rdx, rdy, st.min_t);
+            st.p0    = st.p1;
+            st.p1    = OKPOLY_NONE;
+        }
+        const float t_exit = w.exitT();
+        if (__builtin_fminf(st.min_t, w.t_out) <= t_exit)
+            return {st.min_t, t_exit, true};
+        if (t_exit >= t_b)
+            return {st.min_t, t_exit, false};
+        if (!w.advance(g))
+            return {st.min_t, OK_SENSOR_RANGE, true};
+        h = h_next;
+    }
+    return {st.min_t, OK_SENSOR_RANGE, true};
+}
+
+// First-hit parameter of one whole ray, compact form.
 template <bool kCount>
 OKRC_HD float ok_cast_ray_poly(const OkPolyView &v,
                                const float       ox,
@@ -351,79 +445,5 @@ OKRC_HD float ok_cast_ray_poly(const OkPolyView &v,
                                uint32_t         *cells,
                                uint32_t         *points)
 {
-    const OkGridGeom &g = v.g;
-    OkWalk            w;
-    if (!w.init(g, ox, oy, rdx, rdy))
-        return OK_SENSOR_RANGE;
-    const float tol = v.side_tol;
-    OkPending   st{OKPOLY_NONE, OKPOLY_NONE, OK_SENSOR_RANGE};
-    uint32_t    h     = v.hdr[w.iy * g.nx + w.ix];
-    int         guard = g.nx + g.ny + 2; // the walk visits at most nx + ny cells: termination is unconditional
-    bool        done  = false;
-    while (!done)
-    {
-        // ---- phase A: walk cells and evaluate points until a segment survives the side rule -------------
-        // (On the GPU every lane of the wave leaves this loop before any lane enters phase B, so the costly
-        // exact tests below run once per "round" for all lanes that need them, not once per cell.)
-        while (true)
-        {
-            // header of the cell the walk would enter next (clamped; unused if the walk ends first)
-            const bool go_x = w.tmax_x < w.tmax_y;
-            int        nx_i = w.ix + (go_x ? w.step_x : 0);
-            int        ny_i = w.iy + (go_x ? 0 : w.step_y);
-            nx_i            = nx_i < 0 ? 0 : (nx_i >= g.nx ? g.nx - 1 : nx_i);
-            ny_i            = ny_i < 0 ? 0 : (ny_i >= g.ny ? g.ny - 1 : ny_i);
-            const uint32_t h_next = v.hdr[ny_i * g.nx + nx_i];
-
-            uint32_t       k     = h & OKPOLY_IDX_MASK;
-            const uint32_t k_end = k + (h >> OKPOLY_IDX_BITS);
-            if (kCount)
-            {
-                *cells += 1;
-                *points += (h >> OKPOLY_IDX_BITS);
-            }
-            float s_prev = 0.F;
-            bool  first  = true;
-            for (; k < k_end; k += 2)
-            {
-                const OkPointPair pp = *reinterpret_cast<const OkPointPair *>(&v.slots[k]);
-                const float       sa = ok_side(pp.a, ox, oy, rdx, rdy);
-                const float       sb = ok_side(pp.b, ox, oy, rdx, rdy);
-                s_prev               = first ? sa : s_prev; // the cell's first slot has no predecessor
-                first                = false;
-                const bool ka        = !ok_same_side(s_prev, sa, tol);
-                const bool kb        = !ok_same_side(sa, sb, tol);
-                if (ka | kb)
-                {
-                    if (ka)
-                        st = okPark<kCount>(v, k - 1U, st, ox, oy, rdx, rdy, tests);
-                    if (kb)
-                        st = okPark<kCount>(v, k, st, ox, oy, rdx, rdy, tests);
-                }
-                s_prev = sb;
-            }
-            h = h_next;
-            if (st.p0 != OKPOLY_NONE)
-                break; // something to test exactly: leave the walk, stay in this cell
-            if (__builtin_fminf(st.min_t, w.t_out) <= w.exitT() || !w.advance(g) || --guard <= 0)
-            {
-                done = true;
-                break;
-            }
-        }
-        // ---- phase B: exact tests of the parked segments, then this cell's termination check ---------------
-        if (!done)
-        {
-            if (kCount)
-                *tests += (st.p1 != OKPOLY_NONE) ? 2 : 1;
-            st.min_t = okExactSlot(v, st.p0, ox, oy, rdx, rdy, st.min_t);
-            if (st.p1 != OKPOLY_NONE)
-                st.min_t = okExactSlot(v, st.p1, ox, oy, rdx, rdy, st.min_t);
-            st.p0 = OKPOLY_NONE;
-            st.p1 = OKPOLY_NONE;
-            if (__builtin_fminf(st.min_t, w.t_out) <= w.exitT() || !w.advance(g) || --guard <= 0)
-                done = true;
-        }
-    }
-    return st.min_t;
+    return ok_cast_poly_interval<kCount>(v, ox, oy, rdx, rdy, 0.0F, OKRC_INF, tests, cells, points).min_t;
 }

@@ -23,6 +23,11 @@ namespace
 thread_local std::string g_create_error = "";
 
 constexpr size_t kLdsBudget = 160U * 1024U; // one workgroup may take the whole CU's LDS on gfx950
+// LDS the cooperative kernel needs besides the image: 6 floats + 1 word per lane, 2 counters (okenv_kernels.h)
+constexpr size_t coopBytes(const size_t block_threads)
+{
+    return 28U * block_threads + 16U;
+}
 
 struct EventPair
 {
@@ -51,6 +56,8 @@ struct okenv
     OkDeviceState st{};
     std::vector<void *> allocations;
     int         block_threads{1024}, grid_blocks{1};
+    bool        coop{false};        // workgroup-cooperative two-phase kernel (LDS form, one ray per lane)
+    float       phase1_range{48.F}; // T1 of the cooperative kernel [px]
     std::string last_error;
     bool        timing{false};
     std::vector<EventPair> events;      // recorded pairs awaiting resolution
@@ -204,7 +211,11 @@ int launchStep(okenv *h, const OkStepParams &p)
     switch (h->grid_mode)
     {
     case kGridLds:
-        hipLaunchKernelGGL(okStepKernel<kGridLds>, grid, block, h->image_bytes, h->stream, p);
+        if (h->coop)
+            hipLaunchKernelGGL(okStepCoopKernel, grid, block, h->image_bytes + coopBytes(h->block_threads), h->stream, p,
+                               static_cast<uint32_t>(h->image_bytes), h->phase1_range);
+        else
+            hipLaunchKernelGGL(okStepKernel<kGridLds>, grid, block, h->image_bytes, h->stream, p);
         break;
     case kGridGlobal:
         hipLaunchKernelGGL(okStepKernel<kGridGlobal>, grid, block, 0, h->stream, p);
@@ -280,7 +291,7 @@ extern "C"
         // ---- grid ------------------------------------------------------------------------------------
         const OkSeg *segs = reinterpret_cast<const OkSeg *>(segments_xyxy);
         bool         fits = false;
-        h->grid           = okBuildGridAuto(segs, static_cast<size_t>(num_segments), grid_cell, kLdsBudget, &fits, &h->poly);
+        h->grid = okBuildGridAuto(segs, static_cast<size_t>(num_segments), grid_cell, kLdsBudget - coopBytes(1024), &fits, &h->poly);
         if (flags & OKENV_FLAG_BRUTE_FORCE)
             h->grid_mode = kGridBrute;
         else if (!fits || (flags & OKENV_FLAG_FORCE_GLOBAL_GRID))
@@ -304,9 +315,18 @@ extern "C"
             OK_HIP(nullptr, hipStreamSynchronize(h->stream));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepKernel<kGridLds>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->image_bytes)));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                static_cast<int>(h->image_bytes + coopBytes(1024))));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okDebugCastKernel<kGridLds>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->image_bytes)));
         }
+#if defined(OKENV_STAMPS)
+        if (h->grid_mode == kGridLds)
+        { // diagnostic build: d_refs32 doubles as the stamp buffer (6 x u64 per wave)
+            if ((rc = devAlloc(h, &h->d_refs32, static_cast<size_t>(num_agents) * 64U / 64U * 12U + 1024U)) != OKENV_OK)
+                return fail(nullptr, rc, h->last_error);
+        }
+#endif
         else if (h->grid_mode == kGridGlobal)
         {
             if ((rc = devAlloc(h, &h->d_refs32, h->grid.refs.size())) != OKENV_OK ||
@@ -340,6 +360,15 @@ extern "C"
             per_block = 1024;
         h->block_threads = static_cast<int>(per_block);
         h->grid_blocks   = static_cast<int>((total_lanes + per_block - 1) / per_block);
+        h->coop          = h->grid_mode == kGridLds && h->rays_per_lane == 1;
+        if (const char *env_coop = std::getenv("OKENV_COOP")) // tuning/ablation knob: 0 = every lane walks its own ray to the end
+            h->coop = h->coop && std::atoi(env_coop) != 0;
+        if (const char *env_t1 = std::getenv("OKENV_PHASE1_RANGE"))
+        {
+            const float t1 = static_cast<float>(std::atof(env_t1));
+            if (t1 > 0.F)
+                h->phase1_range = t1;
+        }
         OK_HIP(nullptr, hipStreamSynchronize(h->stream));
         *out = hp.release();
         return OKENV_OK;
@@ -779,6 +808,15 @@ extern "C"
         std::memcpy(out_xyxy, t->segments.data(), t->segments.size() * sizeof(Segment2d));
         return OKENV_OK;
     }
+
+#if defined(OKENV_STAMPS)
+    __attribute__((visibility("default"))) int okenv_debug_stamps(okenv_t h, unsigned long long *out, int waves)
+    {
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        OK_HIP(h, hipMemcpy(out, h->d_refs32, sizeof(unsigned long long) * 6U * waves, hipMemcpyDeviceToHost));
+        return OKENV_OK;
+    }
+#endif
 
     // ---- device self-checks ----------------------------------------------------------------------------------
 

@@ -107,11 +107,7 @@ __device__ __forceinline__ float okCastRay(const OkStepParams &p,
 {
     if (kMode == kGridLds)
     {
-#if defined(OKENV_ABLATE) && OKENV_ABLATE == 1
-        return OK_SENSOR_RANGE * (0.5F + 0.25F * rdx); // timing experiment only: no raycast at all
-#else
         return ok_cast_ray_poly<false>(lds_view, ox, oy, rdx, rdy, nullptr, nullptr, nullptr);
-#endif
     }
     else if (kMode == kGridGlobal)
     {
@@ -147,20 +143,174 @@ __device__ __forceinline__ void okStageImage(const OkStepParams &p, unsigned cha
     __syncthreads();
 }
 
+// Per-agent state carried in registers across the steps of one launch (every lane of the agent's group holds a
+// copy; lane 0 of the group writes it back).
+struct OkAgentRegs
+{
+    float    pos_x, pos_y, rot, speed, acc, thr, steer;
+    int      mode;
+    bool     crashed, timed_out, disp_to;
+    uint32_t disp_ctr;
+    float    disp_x, disp_y;
+};
+
+__device__ __forceinline__ OkAgentRegs okLoadAgent(const OkDeviceState &st, const int a)
+{
+    OkAgentRegs r;
+    r.pos_x     = st.pos_x[a];
+    r.pos_y     = st.pos_y[a];
+    r.rot       = st.rot[a];
+    r.speed     = st.speed[a];
+    r.acc       = st.acc[a];
+    r.thr       = st.thr[a];
+    r.steer     = st.steer[a];
+    r.mode      = st.mode[a];
+    r.crashed   = st.crashed[a] != 0;
+    r.timed_out = st.timed_out[a] != 0;
+    r.disp_to   = st.disp_to[a] != 0;
+    r.disp_ctr  = st.disp_ctr[a];
+    r.disp_x    = st.disp_x[a];
+    r.disp_y    = st.disp_y[a];
+    return r;
+}
+
+__device__ __forceinline__ void okStoreAgent(const OkDeviceState &st, const int a, const OkAgentRegs &r)
+{
+    st.pos_x[a]     = r.pos_x;
+    st.pos_y[a]     = r.pos_y;
+    st.rot[a]       = r.rot;
+    st.speed[a]     = r.speed;
+    st.acc[a]       = r.acc;
+    st.thr[a]       = r.thr;
+    st.steer[a]     = r.steer;
+    st.crashed[a]   = r.crashed ? 1 : 0;
+    st.timed_out[a] = r.timed_out ? 1 : 0;
+    st.disp_to[a]   = r.disp_to ? 1 : 0;
+    st.disp_ctr[a]  = r.disp_ctr;
+    st.disp_x[a]    = r.disp_x;
+    st.disp_y[a]    = r.disp_y;
+}
+
+// Everything Environment::step does to one agent BEFORE the collision pass (Environment.cpp:128-142), preceded by
+// the optional bench driver (reset of crashed agents + Philox action).
+__device__ __forceinline__ void okAgentPreStep(const OkStepParams &p, OkAgentRegs &r, const int a, const int s)
+{
+    if (p.action_source == kActionsPhiloxReset)
+    {
+        const ok_random_action ra =
+            ok_draw_random_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s));
+        if (r.crashed)
+        {
+            // Agent::reset (Agent.cpp:123-135); DisplacementStats deliberately untouched
+            const uint32_t idx = ok_index_from_word(ra.reset_word, static_cast<uint32_t>(p.P));
+            r.pos_x            = p.cx[idx];
+            r.pos_y            = p.cy[idx];
+            r.rot              = p.chead[idx];
+            r.acc              = 0.F;
+            r.speed            = 0.F;
+            r.crashed          = false;
+            r.timed_out        = false;
+        }
+        r.thr   = ra.throttle;
+        r.steer = ra.steer;
+    }
+    if (p.do_move && !r.crashed)
+    {
+        bool moved = true;
+        if (r.mode == 0)
+        { // moveViaVelocity (Agent.cpp:108-119)
+            r.rot += r.steer;
+            r.speed = r.thr;
+        }
+        else if (r.mode == 1)
+        { // moveViaAcceleration (Agent.cpp:82-98)
+            r.rot += r.steer;
+            r.acc += r.thr;
+            r.speed += (r.acc * OK_DT);
+            r.speed = (r.speed < 0.F) ? 0.F : r.speed;
+            r.speed = (r.speed > OK_SPEED_LIMIT) ? OK_SPEED_LIMIT : r.speed;
+        }
+        else
+        {
+            moved = false; // MANUAL: empty in the reference
+        }
+        if (moved)
+        {
+            float sn, cs;
+            ok_sincosf(OK_DEG2RAD * r.rot, &sn, &cs);
+            const float dx = cs * r.speed * OK_DT;
+            r.pos_x += dx;
+            const float dy = sn * r.speed * OK_DT;
+            r.pos_y += dy;
+        }
+        // checkAndUpdateStandstill (Environment.cpp:16-39)
+        if (r.disp_ctr == 0U)
+        {
+            r.disp_x   = r.pos_x;
+            r.disp_y   = r.pos_y;
+            r.disp_to  = false;
+            r.disp_ctr = 1U;
+        }
+        else if (r.disp_ctr >= OK_DISP_PERIOD)
+        {
+            const float ddx = r.pos_x - r.disp_x, ddy = r.pos_y - r.disp_y;
+            const float d2  = ddx * ddx + ddy * ddy;
+            if (d2 < OK_DISP_THRESH2)
+                r.disp_to = true;
+            r.disp_ctr = 0U;
+        }
+        else
+        {
+            r.disp_to = false;
+            ++r.disp_ctr;
+        }
+        if (r.disp_to)
+        {
+            r.crashed   = true;
+            r.timed_out = true;
+        }
+    }
+}
+
+// Hit transform of one ray (CollisionChecker.cu:144-166): writes sensor_hits_ (robot frame) and its norm, returns the
+// squared norm for the crash test.
+__device__ __forceinline__ float
+okRayEpilogue(const OkDeviceState &st, const long k, const float hx, const float hy, const float ox, const float oy, const float sr, const float cr)
+{
+    const float xt = hx - ox;
+    const float yt = hy - oy;
+    const float rx = xt * cr - yt * sr;
+    const float ry = xt * sr + yt * cr;
+    const float n2 = rx * rx + ry * ry;
+    st.rel_x[k]    = rx;
+    st.rel_y[k]    = ry;
+    st.dist[k]     = __builtin_sqrtf(n2);
+    return n2;
+}
+
+template <int kMode>
+__device__ __forceinline__ OkPolyView okSetupView(const OkStepParams &p, unsigned char *lds)
+{
+    OkPolyView view{};
+    if (kMode == kGridLds)
+    {
+        okStageImage(p, lds);
+        view.g        = p.geom;
+        view.slots    = reinterpret_cast<const OkPoint *>(lds);
+        view.hdr      = reinterpret_cast<const uint32_t *>(lds + p.off_hdr);
+        view.brk      = reinterpret_cast<const uint32_t *>(lds + p.off_brk);
+        view.side_tol = p.side_tol;
+    }
+    return view;
+}
+
+// Generic step kernel: every lane casts its own ray(s) from start to end.  Used for the global-memory and
+// brute-force forms, and for fans wider than 64 rays.
 template <int kMode>
 __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
-    OkPolyView view{};
-    if (kMode == kGridLds)
-    {
-        okStageImage(p, ok_lds);
-        view.g        = p.geom;
-        view.slots    = reinterpret_cast<const OkPoint *>(ok_lds);
-        view.hdr      = reinterpret_cast<const uint32_t *>(ok_lds + p.off_hdr);
-        view.brk      = reinterpret_cast<const uint32_t *>(ok_lds + p.off_brk);
-        view.side_tol = p.side_tol;
-    }
+    const OkPolyView view = okSetupView<kMode>(p, ok_lds);
 
     const int  G     = p.G;
     const long gl    = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -169,169 +319,211 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
     // Lanes past the last agent stay in the loop (shuffles need the whole group) but never touch memory.
     const bool agent_ok = agent < p.N;
     const int  a        = agent_ok ? agent : 0;
-
-    // ---- agent state: one broadcast load per field, carried in registers across the launch ---------
-    float    pos_x = p.st.pos_x[a], pos_y = p.st.pos_y[a], rot = p.st.rot[a];
-    float    speed = p.st.speed[a], acc = p.st.acc[a];
-    float    thr = p.st.thr[a], steer = p.st.steer[a];
-    const int mode = p.st.mode[a];
-    bool     crashed = p.st.crashed[a] != 0, timed_out = p.st.timed_out[a] != 0, disp_to = p.st.disp_to[a] != 0;
-    uint32_t disp_ctr = p.st.disp_ctr[a];
-    float    disp_x = p.st.disp_x[a], disp_y = p.st.disp_y[a];
+    OkAgentRegs ag      = okLoadAgent(p.st, a);
 
     for (int s = 0; s < p.n_steps; ++s)
     {
-        // ---- bench driver: reset crashed agents, draw the step's action --------
-        if (p.action_source == kActionsPhiloxReset)
-        {
-            const ok_random_action ra =
-                ok_draw_random_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s));
-            if (crashed)
-            {
-                // Agent::reset (Agent.cpp:123-135); DisplacementStats deliberately untouched
-                const uint32_t idx = ok_index_from_word(ra.reset_word, static_cast<uint32_t>(p.P));
-                pos_x              = p.cx[idx];
-                pos_y              = p.cy[idx];
-                rot                = p.chead[idx];
-                acc                = 0.F;
-                speed              = 0.F;
-                crashed            = false;
-                timed_out          = false;
-            }
-            thr   = ra.throttle;
-            steer = ra.steer;
-        }
-
-        // ---- 1) kinematics + standstill (Environment.cpp:128-142) --------------------------------------
-        if (p.do_move && !crashed)
-        {
-            bool moved = true;
-            if (mode == 0)
-            { // moveViaVelocity
-                rot += steer;
-                speed = thr;
-            }
-            else if (mode == 1)
-            { // moveViaAcceleration
-                rot += steer;
-                acc += thr;
-                speed += (acc * OK_DT);
-                speed = (speed < 0.F) ? 0.F : speed;
-                speed = (speed > OK_SPEED_LIMIT) ? OK_SPEED_LIMIT : speed;
-            }
-            else
-            {
-                moved = false; // MANUAL: empty in the reference
-            }
-            if (moved)
-            {
-                float sn, cs;
-                ok_sincosf(OK_DEG2RAD * rot, &sn, &cs);
-                const float dx = cs * speed * OK_DT;
-                pos_x += dx;
-                const float dy = sn * speed * OK_DT;
-                pos_y += dy;
-            }
-            // checkAndUpdateStandstill
-            if (disp_ctr == 0U)
-            {
-                disp_x   = pos_x;
-                disp_y   = pos_y;
-                disp_to  = false;
-                disp_ctr = 1U;
-            }
-            else if (disp_ctr >= OK_DISP_PERIOD)
-            {
-                const float ddx = pos_x - disp_x, ddy = pos_y - disp_y;
-                const float d2  = ddx * ddx + ddy * ddy;
-                if (d2 < OK_DISP_THRESH2)
-                    disp_to = true;
-                disp_ctr = 0U;
-            }
-            else
-            {
-                disp_to = false;
-                ++disp_ctr;
-            }
-            if (disp_to)
-            {
-                crashed   = true;
-                timed_out = true;
-            }
-        }
-
-        // ---- 2) collision pass (CollisionChecker.cu:113-174) -----------------------------------------
+        okAgentPreStep(p, ag, a, s);
+        // ---- collision pass (CollisionChecker.cu:113-174) ------------------------------------------------
         float sr, cr;
-        ok_sincosf(OK_DEG2RAD * rot, &sr, &cr);
-        const float ox     = pos_x + p.sensor_offset * cr;
-        const float oy     = pos_y + p.sensor_offset * sr;
-        const bool  active = !crashed;
+        ok_sincosf(OK_DEG2RAD * ag.rot, &sr, &cr);
+        const float ox     = ag.pos_x + p.sensor_offset * cr;
+        const float oy     = ag.pos_y + p.sensor_offset * sr;
+        const bool  active = !ag.crashed;
         float       min_d2 = OK_SENSOR_RANGE * OK_SENSOR_RANGE;
         for (int q = 0; q < p.rays_per_lane; ++q)
         {
             const int  r      = rlane + q * G;
             const bool ray_ok = agent_ok && (r < p.R);
             const long k      = static_cast<long>(a) * p.R + (ray_ok ? r : 0);
-            float      hx, hy;
-            if (active)
-            {
-                float rdy = 0.F, rdx = 1.F, min_t = OK_SENSOR_RANGE;
-                if (ray_ok)
-                {
-                    const float angle = OK_DEG2RAD * (rot + p.ray_deg[r]);
-                    ok_sincosf(angle, &rdy, &rdx);
-                    min_t = okCastRay<kMode>(p, view, ox, oy, rdx, rdy);
-                }
-                hx = ox + min_t * rdx;
-                hy = oy + min_t * rdy;
-                if (ray_ok)
-                {
-                    p.st.hit_x[k] = hx;
-                    p.st.hit_y[k] = hy;
-                }
-            }
-            else
-            {
-                // stale world hit point of a crashed agent
-                hx = ray_ok ? p.st.hit_x[k] : ox;
-                hy = ray_ok ? p.st.hit_y[k] : oy;
-            }
-            const float xt = hx - ox;
-            const float yt = hy - oy;
-            const float rx = xt * cr - yt * sr;
-            const float ry = xt * sr + yt * cr;
-            const float n2 = rx * rx + ry * ry;
+            float      hx = ox, hy = oy;
             if (ray_ok)
             {
-                p.st.rel_x[k] = rx;
-                p.st.rel_y[k] = ry;
-                p.st.dist[k]  = __builtin_sqrtf(n2);
+                if (active)
+                {
+                    float rdy, rdx;
+                    ok_sincosf(OK_DEG2RAD * (ag.rot + p.ray_deg[r]), &rdy, &rdx);
+                    const float min_t = okCastRay<kMode>(p, view, ox, oy, rdx, rdy);
+                    hx                = ox + min_t * rdx;
+                    hy                = oy + min_t * rdy;
+                    p.st.hit_x[k]     = hx;
+                    p.st.hit_y[k]     = hy;
+                }
+                else
+                { // stale world hit point of a crashed agent
+                    hx = p.st.hit_x[k];
+                    hy = p.st.hit_y[k];
+                }
+                const float n2 = okRayEpilogue(p.st, k, hx, hy, ox, oy, sr, cr);
                 if (n2 < min_d2)
                     min_d2 = n2;
             }
         }
         min_d2 = okGroupMin(min_d2, G);
         if (min_d2 < OK_CRASH_DIST2)
-            crashed = true;
+            ag.crashed = true;
     }
-
-    // ---- write the agent state back once (lane 0 of each group) ----------------------------------------
     if (agent_ok && rlane == 0)
+        okStoreAgent(p.st, a, ag);
+}
+
+// Workgroup-cooperative step kernel for the LDS form (one ray per lane).
+//
+// A fan's rays differ in length by an order of magnitude (median first hit ~25 px, sensor range 200 px), and a
+// wave costs as much as its longest ray, so with "each lane walks its own ray to the end" three quarters of the
+// lane-cycles idle.  Here the collision pass of a step runs in two phases:
+//   phase 1  every lane walks its own ray over [0, T1] only (a few cells).  Most rays end there.
+//   phase 2  the unfinished rays of the whole workgroup are compacted into an LDS list and each is cut into m equal
+//            parameter intervals, m = min(8, lanes / unfinished); every (ray, interval) pair goes to one lane of the
+//            workgroup, which walks just that interval and folds its result into the ray's LDS slot with an LDS
+//            atomic min.  The intervals beyond a ray's true first hit are speculative work done by lanes that would
+//            otherwise idle; the critical path of a step drops from ~20 cells to ~4 + ~4.
+// Exactness: ok_cast_poly_interval's contract (ok_raycast.h) -- the min over the intervals' results carries the same
+// bits as a single walk.  Two workgroup barriers per step; agents stay independent across workgroups.
+//
+// LDS: [ image | recs: 6 floats per lane | result: 1 word per lane | 2 counters ]
+struct OkCoopLds
+{
+    float    *rec;     // ox, oy, rdx, rdy, t_reached, owner lane (as int bits)
+    int      *result;  // first-hit parameter bits per owner lane (non-negative floats order like ints; -0.0 sorts first)
+    uint32_t *counter; // [2], alternating by step parity
+};
+
+__global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, const uint32_t off_coop, const float phase1_range)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
+    OkCoopLds co;
+    co.rec     = reinterpret_cast<float *>(ok_lds + off_coop);
+    co.result  = reinterpret_cast<int *>(co.rec + 6 * blockDim.x);
+    co.counter = reinterpret_cast<uint32_t *>(co.result + blockDim.x);
+    if (threadIdx.x < 2)
+        co.counter[threadIdx.x] = 0U;
+    const OkPolyView view = okSetupView<kGridLds>(p, ok_lds); // ends with a barrier
+
+    const int  G        = p.G;
+    const int  tid      = static_cast<int>(threadIdx.x);
+    const long gl       = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int  agent    = static_cast<int>(gl / G);
+    const int  r        = static_cast<int>(gl % G);
+    const bool agent_ok = agent < p.N;
+    const int  a        = agent_ok ? agent : 0;
+    const bool ray_ok   = agent_ok && (r < p.R);
+    const long k        = static_cast<long>(a) * p.R + (ray_ok ? r : 0);
+    const float ray_deg = p.ray_deg[ray_ok ? r : 0];
+    OkAgentRegs ag      = okLoadAgent(p.st, a);
+
+#if defined(OKENV_STAMPS)
+    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+#define OK_STAMP(i)                                                                                                    \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                  \
+        acc[i] += now_ - last_;                                                                                        \
+        last_ = now_;                                                                                                  \
+    } while (0)
+    unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#else
+#define OK_STAMP(i)
+#endif
+    for (int s = 0; s < p.n_steps; ++s)
     {
-        p.st.pos_x[a]     = pos_x;
-        p.st.pos_y[a]     = pos_y;
-        p.st.rot[a]       = rot;
-        p.st.speed[a]     = speed;
-        p.st.acc[a]       = acc;
-        p.st.thr[a]       = thr;
-        p.st.steer[a]     = steer;
-        p.st.crashed[a]   = crashed ? 1 : 0;
-        p.st.timed_out[a] = timed_out ? 1 : 0;
-        p.st.disp_to[a]   = disp_to ? 1 : 0;
-        p.st.disp_ctr[a]  = disp_ctr;
-        p.st.disp_x[a]    = disp_x;
-        p.st.disp_y[a]    = disp_y;
+        const int par = s & 1;
+        okAgentPreStep(p, ag, a, s);
+        float sr, cr;
+        ok_sincosf(OK_DEG2RAD * ag.rot, &sr, &cr);
+        const float ox     = ag.pos_x + p.sensor_offset * cr;
+        const float oy     = ag.pos_y + p.sensor_offset * sr;
+        const bool  casts  = ray_ok && !ag.crashed;
+        float       rdx = 1.F, rdy = 0.F;
+
+        OK_STAMP(0);
+        // ---- phase 1: own ray over [0, T1] --------------------------------------------------------------
+        if (casts)
+        {
+            ok_sincosf(OK_DEG2RAD * (ag.rot + ray_deg), &rdy, &rdx);
+            const OkIntervalResult r1 =
+                ok_cast_poly_interval<false>(view, ox, oy, rdx, rdy, 0.F, phase1_range, nullptr, nullptr, nullptr);
+            co.result[tid] = __float_as_int(r1.min_t);
+            if (!r1.conclusive)
+            {
+                const uint32_t slot = atomicAdd(&co.counter[par], 1U);
+                float         *rec  = co.rec + 6U * slot;
+                rec[0]              = ox;
+                rec[1]              = oy;
+                rec[2]              = rdx;
+                rec[3]              = rdy;
+                rec[4]              = r1.t_reached;
+                rec[5]              = __int_as_float(tid);
+            }
+        }
+        OK_STAMP(1);
+        __syncthreads();
+        OK_STAMP(2);
+
+        // ---- phase 2: (unfinished ray, interval) pairs over all lanes of the workgroup ------------------------
+        const uint32_t unfinished = co.counter[par];
+        if (tid == 0)
+            co.counter[par ^ 1] = 0U; // next step's counter; nobody touches it until the next barrier
+        if (unfinished != 0U)
+        {
+            uint32_t m = blockDim.x / unfinished;
+            m          = m > 8U ? 8U : m;
+            for (uint32_t task = tid; task < unfinished * m; task += blockDim.x)
+            {
+                const uint32_t ray = task / m;
+                const uint32_t j   = task - ray * m;
+                const float   *rec = co.rec + 6U * ray;
+                const float    t0  = rec[4];
+                const float    dt  = (OK_SENSOR_RANGE - t0) / static_cast<float>(m);
+                const float    ta  = t0 + static_cast<float>(j) * dt;
+                const float    tb  = (j + 1U == m) ? OKRC_INF : t0 + static_cast<float>(j + 1U) * dt;
+                const OkIntervalResult r2 =
+                    ok_cast_poly_interval<false>(view, rec[0], rec[1], rec[2], rec[3], ta, tb, nullptr, nullptr, nullptr);
+                if (r2.min_t < OK_SENSOR_RANGE)
+                    atomicMin(&co.result[__float_as_int(rec[5])], __float_as_int(r2.min_t));
+            }
+        }
+        OK_STAMP(3);
+        __syncthreads();
+        OK_STAMP(4);
+
+        // ---- hit point, transform, crash test (CollisionChecker.cu:69-70,144-172) -----------------------------------
+        float min_d2 = OK_SENSOR_RANGE * OK_SENSOR_RANGE;
+        if (ray_ok)
+        {
+            float hx, hy;
+            if (casts)
+            {
+                const float min_t = __int_as_float(co.result[tid]);
+                hx                = ox + min_t * rdx;
+                hy                = oy + min_t * rdy;
+                p.st.hit_x[k]     = hx;
+                p.st.hit_y[k]     = hy;
+            }
+            else
+            { // stale world hit point of a crashed agent
+                hx = p.st.hit_x[k];
+                hy = p.st.hit_y[k];
+            }
+            min_d2 = okRayEpilogue(p.st, k, hx, hy, ox, oy, sr, cr);
+            min_d2 = (min_d2 < OK_SENSOR_RANGE * OK_SENSOR_RANGE) ? min_d2 : OK_SENSOR_RANGE * OK_SENSOR_RANGE;
+        }
+        min_d2 = okGroupMin(min_d2, G);
+        if (min_d2 < OK_CRASH_DIST2)
+            ag.crashed = true;
+        OK_STAMP(5);
     }
+#if defined(OKENV_STAMPS)
+    if ((threadIdx.x & 63) == 0)
+    { // diagnostic build only: per-wave cycle sums go to the (otherwise unused here) rel_x tail... a dedicated buffer
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(const_cast<uint32_t *>(p.g_refs32));
+        const long          w   = gl >> 6;
+        for (int i = 0; i < 6; ++i)
+            dbg[w * 6 + i] = acc[i];
+    }
+#endif
+    if (agent_ok && r == 0)
+        okStoreAgent(p.st, a, ag);
 }
 
 // ---- small service kernels ------------------------------------------------------------------------------

@@ -33,7 +33,7 @@ extern "C"
         v.start = gh.start.data();
         OkPolyImage img = okBuildPolyImage(segs, static_cast<size_t>(S), gh);
         OkPolyView  pv{};
-        if (form == 1)
+        if (form >= 1)
         {
             if (!img.ok)
                 return -1;
@@ -59,7 +59,28 @@ extern "C"
             ok_sincosf(angle_rad[i], &s, &c);
             uint32_t tests = 0, cells = 0, points = 0;
             if (form == 1)
+            {
                 out_t[i] = ok_cast_ray_poly<true>(pv, ox[i], oy[i], c, s, &tests, &cells, &points);
+            }
+            else if (form >= 2)
+            { // the kernel's two-phase decomposition: [0, T1], then m equal sub-intervals of what is left
+                const float T1 = 48.0F;
+                const int   m  = form; // 2..8 sub-intervals
+                OkIntervalResult r1 = ok_cast_poly_interval<true>(pv, ox[i], oy[i], c, s, 0.0F, T1, &tests, &cells, &points);
+                float best = r1.min_t;
+                if (!r1.conclusive)
+                {
+                    const float dt = (OK_SENSOR_RANGE - r1.t_reached) / (float)m;
+                    for (int j = 0; j < m; ++j)
+                    {
+                        const float ta = r1.t_reached + (float)j * dt;
+                        const float tb = (j == m - 1) ? OKRC_INF : ta + dt;
+                        OkIntervalResult r2 = ok_cast_poly_interval<true>(pv, ox[i], oy[i], c, s, ta, tb, &tests, &cells, &points);
+                        best = r2.min_t < best ? r2.min_t : best;
+                    }
+                }
+                out_t[i] = best;
+            }
             else
                 out_t[i] = ok_cast_ray_grid<true>(v, ox[i], oy[i], c, s, &tests, &cells);
             if (out_tests)
