@@ -13,7 +13,7 @@
 
 #include "Typedefs.h"
 
-class RaceTrack
+class OKENV_CLASS RaceTrack
 {
   public:
     static constexpr size_t kStartingIdx{3}; // centre-line index agents start from

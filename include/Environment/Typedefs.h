@@ -10,6 +10,9 @@
 #include <math.h>
 #include <vector>
 
+// the library is built with -fvisibility=hidden; the drop-in classes are its C++ surface
+#define OKENV_CLASS __attribute__((visibility("default")))
+
 constexpr int kScreenWidth  = 1600; // reference Environment/Typedefs.h:7
 constexpr int kScreenHeight = 1400; // reference Environment/Typedefs.h:8
 

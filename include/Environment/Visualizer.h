@@ -1,0 +1,42 @@
+// Visualizer.h -- headless stand-in for the reference's Raylib visualizer (reference Environment/Visualizer.h).
+//
+// The hot path runs with the visualizer compiled out (BASELINE.json north_star); this class keeps the members
+// callers touch (`env.visualizer_->user_draw_callback_ = ...`, setAgentToFollow, camera_) compiling.  render()
+// draws nothing; it only invokes the user callback so that callers that count frames or log inside it keep working.
+#pragma once
+
+#include <functional>
+#include <vector>
+
+#include "Agent.h"
+#include "RaceTrack.h"
+
+class CollisionChecker;
+
+namespace env
+{
+class Visualizer
+{
+  public:
+    explicit Visualizer(bool hidden_window = false) : hidden_window_(hidden_window) {}
+
+    void setAgentToFollow(const Agent *agent) { agent_to_follow_ = agent; }
+    void enableDrawingSensorRays() { draw_rays_ = true; }
+    void disableDrawingSensorRays() { draw_rays_ = false; }
+    void close() {}
+
+    void render(const RaceTrack & /*track*/, const std::vector<Agent *> & /*agents*/, const CollisionChecker * /*rays*/)
+    {
+        if (user_draw_callback_)
+            user_draw_callback_();
+        ++frames_rendered_;
+    }
+
+  public:
+    std::function<void()> user_draw_callback_{};
+    const Agent          *agent_to_follow_{nullptr};
+    bool                  draw_rays_{true};
+    bool                  hidden_window_{false};
+    unsigned long         frames_rendered_{0};
+};
+} // namespace env

@@ -1,0 +1,424 @@
+// Environment.cpp -- TrackSegments, CollisionChecker and Environment of include/Environment/, hosted on the C ABI
+// of include/okenv.h.  Callers keep mutating their Agent objects between steps (reset(), current_action_), so every
+// step gathers the agents' fields into struct-of-arrays staging buffers, uploads them, runs the fused device step
+// and scatters the results back: the same two PCIe crossings per step the reference pays
+// (reference Environment/CollisionChecker.cu:130,142), but a few hundred bytes per agent instead of 24 B per ray
+// each way, and everything between them is one kernel.  Throughput-oriented callers use the C ABI directly and
+// leave the state on the device.
+#include "Environment/Environment.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <random>
+
+#include "okenv.h"
+#include "okenv_math.h"
+
+namespace
+{
+[[noreturn]] void die(const char *what, okenv_t h)
+{
+    std::cerr << "okenv: " << what << ": " << okenv_last_error(h) << std::endl;
+    std::terminate(); // GOX_ASSERT semantics of the reference: the step path has no recoverable errors
+}
+
+std::mt19937 &rng()
+{
+    static std::mt19937 gen(20260220U);
+    return gen;
+}
+} // namespace
+
+// ---- TrackSegments ------------------------------------------------------------------------------------------
+
+TrackSegments::TrackSegments(const RaceTrack &rt)
+{
+    auto run = [&](const std::vector<Vec2d> &poly) {
+        for (size_t i = 0; i + 1 < poly.size(); ++i)
+            segments_.push_back({poly[i].x, poly[i].y, poly[i + 1].x, poly[i + 1].y});
+    };
+    auto closer = [&](const std::vector<Vec2d> &poly) {
+        segments_.push_back({poly.back().x, poly.back().y, poly.front().x, poly.front().y});
+    };
+    run(rt.left_bound_inner_);
+    run(rt.left_bound_outer_);
+    run(rt.right_bound_inner_);
+    run(rt.right_bound_outer_);
+    if (rt.left_bound_inner_.size() > 1)
+    {
+        closer(rt.left_bound_inner_);
+        closer(rt.right_bound_inner_);
+    }
+    if (rt.left_bound_outer_.size() > 1)
+    {
+        closer(rt.left_bound_outer_);
+        closer(rt.right_bound_outer_);
+    }
+    GOX_ASSERT(!segments_.empty());
+    void *d = nullptr;
+    if (hipMalloc(&d, segments_.size() * sizeof(Segment2d)) == hipSuccess &&
+        hipMemcpy(d, segments_.data(), segments_.size() * sizeof(Segment2d), hipMemcpyHostToDevice) == hipSuccess)
+        d_segments_ = static_cast<Segment2d *>(d);
+    else
+        die("TrackSegments: device upload failed (no usable GPU?)", nullptr);
+}
+
+TrackSegments::~TrackSegments()
+{
+    if (d_segments_)
+        (void)hipFree(d_segments_);
+}
+
+// ---- CollisionChecker ---------------------------------------------------------------------------------------
+
+class CollisionChecker::Impl
+{
+  public:
+    Impl(const Segment2d *segments, const size_t num_segments, const std::vector<Agent *> &agents) : agents_(agents)
+    {
+        GOX_ASSERT(!agents.empty());
+        n_ = static_cast<int>(agents.size());
+        r_ = static_cast<int>(agents[0]->sensor_ray_angles_.size()); // all agents share one fan (CollisionChecker.cu:82)
+        GOX_ASSERT(r_ > 0);
+        // the segments may live on the device (TrackSegments::getDeviceSegments) or on the host
+        std::vector<Segment2d> host(num_segments);
+        if (hipMemcpy(host.data(), segments, num_segments * sizeof(Segment2d), hipMemcpyDefault) != hipSuccess)
+            die("CollisionChecker: cannot read the segment array", nullptr);
+        int device = 0;
+        (void)hipGetDevice(&device);
+        if (okenv_create(&h_, reinterpret_cast<const float *>(host.data()), static_cast<int32_t>(num_segments), n_, r_,
+                         agents[0]->sensor_ray_angles_.data(), device, OKENV_FLAG_NONE, 0.F) != OKENV_OK)
+            die("okenv_create", nullptr);
+        const size_t n = static_cast<size_t>(n_);
+        for (auto *v : {&pos_x_, &pos_y_, &rot_, &speed_, &acc_, &thr_, &steer_, &disp_x_, &disp_y_})
+            v->assign(n, 0.F);
+        for (auto *v : {&mode_, &crashed_, &timed_out_, &disp_to_})
+            v->assign(n, 0);
+        disp_ctr_.assign(n, 0U);
+        hits_.assign(n * r_ * 2U, 0.F);
+        rays_.assign(n * r_, Ray_{0.F, 0.F, 0.F, 0.F, 0.F, true});
+    }
+
+    ~Impl() { okenv_destroy(h_); }
+
+    okenv_state_view view()
+    {
+        okenv_state_view v{};
+        v.pos_x          = pos_x_.data();
+        v.pos_y          = pos_y_.data();
+        v.rot            = rot_.data();
+        v.speed          = speed_.data();
+        v.acc            = acc_.data();
+        v.throttle       = thr_.data();
+        v.steer          = steer_.data();
+        v.mode           = mode_.data();
+        v.crashed        = crashed_.data();
+        v.timed_out      = timed_out_.data();
+        v.disp_ctr       = disp_ctr_.data();
+        v.disp_x         = disp_x_.data();
+        v.disp_y         = disp_y_.data();
+        v.disp_timed_out = disp_to_.data();
+        return v;
+    }
+
+    // Agent objects -> staging -> device.  `stats` (optional) carries Environment's DisplacementStats.
+    void upload(const std::vector<Agent *> &agents, const std::vector<DisplacementStats> *stats)
+    {
+        for (int i = 0; i < n_; ++i)
+        {
+            const Agent *a = agents[i];
+            pos_x_[i]      = a->pos_.x;
+            pos_y_[i]      = a->pos_.y;
+            rot_[i]        = a->rot_;
+            speed_[i]      = a->speed_;
+            acc_[i]        = a->acceleration_;
+            thr_[i]        = a->current_action_.throttle_delta;
+            steer_[i]      = a->current_action_.steering_delta;
+            mode_[i]       = static_cast<uint8_t>(a->movement_mode_);
+            crashed_[i]    = a->crashed_ ? 1 : 0;
+            timed_out_[i]  = a->timed_out_ ? 1 : 0;
+            if (stats)
+            {
+                disp_ctr_[i] = (*stats)[i].displacement_ctr;
+                disp_x_[i]   = (*stats)[i].init_pos.x;
+                disp_y_[i]   = (*stats)[i].init_pos.y;
+                disp_to_[i]  = (*stats)[i].displacement_timed_out ? 1 : 0;
+            }
+        }
+        if (okenv_set_sensor_offset(h_, agents[0]->sensor_offset_) != OKENV_OK)
+            die("okenv_set_sensor_offset", h_);
+        okenv_state_view v = view();
+        if (!stats)
+            v.disp_ctr = nullptr, v.disp_x = nullptr, v.disp_y = nullptr, v.disp_timed_out = nullptr;
+        if (okenv_upload_state(h_, &v) != OKENV_OK)
+            die("okenv_upload_state", h_);
+    }
+
+    void download(const std::vector<Agent *> &agents, std::vector<DisplacementStats> *stats)
+    {
+        okenv_state_view v = view();
+        if (okenv_download_state(h_, &v) != OKENV_OK || okenv_get_hits(h_, hits_.data()) != OKENV_OK)
+            die("okenv_download_state", h_);
+        for (int i = 0; i < n_; ++i)
+        {
+            Agent *a         = agents[i];
+            a->pos_          = {pos_x_[i], pos_y_[i]};
+            a->rot_          = rot_[i];
+            a->speed_        = speed_[i];
+            a->acceleration_ = acc_[i];
+            a->crashed_      = crashed_[i] != 0;
+            a->timed_out_    = timed_out_[i] != 0;
+            a->sensor_hits_.resize(static_cast<size_t>(r_));
+            for (int r = 0; r < r_; ++r)
+            {
+                const size_t k     = (static_cast<size_t>(i) * r_ + r) * 2U;
+                a->sensor_hits_[r] = {hits_[k], hits_[k + 1]};
+            }
+            if (stats)
+            {
+                (*stats)[i].displacement_ctr       = disp_ctr_[i];
+                (*stats)[i].init_pos               = {disp_x_[i], disp_y_[i]};
+                (*stats)[i].displacement_timed_out = disp_to_[i] != 0;
+            }
+        }
+        rays_valid_ = false;
+    }
+
+    // Ray_ view for visualisation, rebuilt on demand from the device state (reference CollisionChecker.cu:115-128)
+    const Ray_ *hostRays()
+    {
+        if (!rays_valid_)
+        {
+            const size_t       nr = static_cast<size_t>(n_) * r_;
+            std::vector<float> hx(nr), hy(nr);
+            if (okenv_get_field(h_, OKENV_F_HIT_X, hx.data()) != OKENV_OK || okenv_get_field(h_, OKENV_F_HIT_Y, hy.data()) != OKENV_OK)
+                die("okenv_get_field", h_);
+            for (int i = 0; i < n_; ++i)
+            {
+                const Agent *a = agents_[i];
+                float        sn, cs;
+                ok_sincosf(OK_DEG2RAD * a->rot_, &sn, &cs);
+                for (int r = 0; r < r_; ++r)
+                {
+                    Ray_ &ray  = rays_[static_cast<size_t>(i) * r_ + r];
+                    ray.x      = a->pos_.x + a->sensor_offset_ * cs;
+                    ray.y      = a->pos_.y + a->sensor_offset_ * sn;
+                    ray.angle  = OK_DEG2RAD * (a->rot_ + agents_[0]->sensor_ray_angles_[r]);
+                    ray.hit_x  = hx[static_cast<size_t>(i) * r_ + r];
+                    ray.hit_y  = hy[static_cast<size_t>(i) * r_ + r];
+                    ray.active = !a->crashed_;
+                }
+            }
+            rays_valid_ = true;
+        }
+        return rays_.data();
+    }
+
+    okenv_t              h_{nullptr};
+    std::vector<Agent *> agents_;
+    int                  n_{0}, r_{0};
+    std::vector<float>    pos_x_, pos_y_, rot_, speed_, acc_, thr_, steer_, disp_x_, disp_y_, hits_;
+    std::vector<uint8_t>  mode_, crashed_, timed_out_, disp_to_;
+    std::vector<uint32_t> disp_ctr_;
+    std::vector<Ray_>     rays_;
+    bool                  rays_valid_{false};
+};
+
+CollisionChecker::CollisionChecker(const Segment2d *d_segments, size_t num_segments, const std::vector<Agent *> &agents)
+    : impl_(std::make_unique<Impl>(d_segments, num_segments, agents))
+{
+}
+
+CollisionChecker::~CollisionChecker() = default;
+
+void CollisionChecker::checkCollision()
+{
+    impl_->upload(impl_->agents_, nullptr);
+    if (okenv_collide(impl_->h_) != OKENV_OK)
+        die("okenv_collide", impl_->h_);
+    impl_->download(impl_->agents_, nullptr);
+}
+
+const Ray_ *CollisionChecker::getHostRays() const
+{
+    return impl_->hostRays();
+}
+
+size_t CollisionChecker::getNumRays() const
+{
+    return static_cast<size_t>(impl_->n_) * impl_->r_;
+}
+
+okenv *CollisionChecker::handle() const
+{
+    return impl_->h_;
+}
+
+void CollisionChecker::uploadAgents(const std::vector<Agent *> &agents)
+{
+    impl_->upload(agents, nullptr);
+}
+
+void CollisionChecker::downloadAgents(const std::vector<Agent *> &agents)
+{
+    impl_->download(agents, nullptr);
+}
+
+// ---- Environment --------------------------------------------------------------------------------------------
+
+namespace
+{
+// Environment needs the Impl's stats-carrying exchange; CollisionChecker.h keeps Impl private, so the two calls go
+// through this friend-free shim: a second state view uploaded/downloaded straight over the C ABI.
+struct StatsExchange
+{
+    std::vector<uint32_t> ctr;
+    std::vector<float>    x, y;
+    std::vector<uint8_t>  to;
+
+    void upload(okenv_t h, const std::vector<DisplacementStats> &s)
+    {
+        const size_t n = s.size();
+        ctr.resize(n), x.resize(n), y.resize(n), to.resize(n);
+        for (size_t i = 0; i < n; ++i)
+        {
+            ctr[i] = s[i].displacement_ctr;
+            x[i]   = s[i].init_pos.x;
+            y[i]   = s[i].init_pos.y;
+            to[i]  = s[i].displacement_timed_out ? 1 : 0;
+        }
+        okenv_state_view v{};
+        v.disp_ctr = ctr.data(), v.disp_x = x.data(), v.disp_y = y.data(), v.disp_timed_out = to.data();
+        if (okenv_upload_state(h, &v) != OKENV_OK)
+            die("okenv_upload_state(stats)", h);
+    }
+    void download(okenv_t h, std::vector<DisplacementStats> &s)
+    {
+        okenv_state_view v{};
+        v.disp_ctr = ctr.data(), v.disp_x = x.data(), v.disp_y = y.data(), v.disp_timed_out = to.data();
+        if (okenv_download_state(h, &v) != OKENV_OK)
+            die("okenv_download_state(stats)", h);
+        for (size_t i = 0; i < s.size(); ++i)
+        {
+            s[i].displacement_ctr       = ctr[i];
+            s[i].init_pos               = {x[i], y[i]};
+            s[i].displacement_timed_out = to[i] != 0;
+        }
+    }
+};
+StatsExchange &statsExchange()
+{
+    static thread_local StatsExchange ex;
+    return ex;
+}
+} // namespace
+
+Environment::Environment(const std::string &race_track_path, const std::vector<Agent *> &agents, const bool draw_rays, const bool hidden_window)
+    : draw_rays_(draw_rays)
+{
+    race_track_     = std::make_unique<RaceTrack>(race_track_path);
+    track_segments_ = std::make_unique<TrackSegments>(*race_track_);
+    visualizer_     = std::make_unique<env::Visualizer>(hidden_window);
+    screen_grabber_ = std::make_unique<ScreenGrabber>(kScreenWidth, kScreenHeight);
+    agents_         = agents;
+    displacement_stats_.resize(agents.size());
+    if (!agents_.empty())
+        ensureChecker();
+}
+
+Environment::Environment(const std::string &race_track_path) : Environment(race_track_path, std::vector<Agent *>{}, true, true) {}
+
+Environment::~Environment() = default;
+
+void Environment::setAgent(Agent *agent)
+{
+    agents_.push_back(agent);
+    displacement_stats_.resize(agents_.size());
+    checker_stale_ = true; // population (and possibly the ray count) changed: rebuild at the next step
+}
+
+void Environment::ensureChecker()
+{
+    if (!checker_stale_ && collision_checker_)
+        return;
+    GOX_ASSERT(!agents_.empty());
+    collision_checker_ = std::make_unique<CollisionChecker>(track_segments_->getDeviceSegments(), track_segments_->getNumSegments(), agents_);
+    const auto &d      = race_track_->track_data_points_;
+    if (okenv_set_centerline(collision_checker_->handle(), d.x_m.data(), d.y_m.data(), race_track_->headings_.data(),
+                             static_cast<int32_t>(d.x_m.size())) != OKENV_OK)
+        die("okenv_set_centerline", collision_checker_->handle());
+    checker_stale_ = false;
+}
+
+void Environment::drawSensorRanges(const std::vector<Vec2d> & /*sensor_hits*/) {}
+
+void Environment::step()
+{
+    ensureChecker();
+    okenv_t h = collision_checker_->handle();
+    collision_checker_->uploadAgents(agents_);
+    statsExchange().upload(h, displacement_stats_);
+    if (okenv_step(h, 1) != OKENV_OK)
+        die("okenv_step", h);
+    collision_checker_->downloadAgents(agents_);
+    statsExchange().download(h, displacement_stats_);
+    visualizer_->render(*race_track_, agents_, draw_rays_ ? collision_checker_.get() : nullptr);
+}
+
+void Environment::seedRandom(const uint32_t seed)
+{
+    rng().seed(seed);
+}
+
+int Environment::randomValue(const int lo, const int hi)
+{
+    return std::uniform_int_distribution<int>(lo, hi)(rng());
+}
+
+int32_t Environment::pickRandomResetTrackIdx() const
+{
+    return randomValue(0, static_cast<int32_t>(race_track_->track_data_points_.x_m.size()) - 1);
+}
+
+void Environment::resetAgent(Agent *agent, const bool pick_random_point, const bool randomize_lane, const bool randomize_heading)
+{
+    const int32_t idx = pick_random_point ? pickRandomResetTrackIdx() : static_cast<int32_t>(RaceTrack::kStartingIdx);
+
+    // heading offset of +-(45 + [0,45]) degrees, the sign alternating from call to call
+    // (reference Environment/Environment.cpp:86-101)
+    float         heading_offset = 0.F;
+    static size_t flip           = 0;
+    if (pick_random_point && randomize_heading)
+    {
+        constexpr float kRange{45.F};
+        const float     magnitude = static_cast<float>(randomValue(0, static_cast<int>(kRange))) + kRange;
+        heading_offset            = (flip % 2 == 0) ? magnitude * -1.F : magnitude;
+        ++flip;
+    }
+
+    const auto &d = race_track_->track_data_points_;
+    float       x = d.x_m[idx], y = d.y_m[idx];
+    if (pick_random_point && randomize_lane)
+    {
+        // lateral position between the inner boundaries, alpha in [0.10, 0.90] (reference :106-113)
+        const Vec2d l     = race_track_->left_bound_inner_[idx];
+        const Vec2d r     = race_track_->right_bound_inner_[idx];
+        const float alpha = static_cast<float>(randomValue(10, 90)) / 100.F;
+        x                 = l.x * alpha + r.x * (1.F - alpha);
+        y                 = l.y * alpha + r.y * (1.F - alpha);
+    }
+    agent->reset({x, y}, race_track_->headings_[idx] + heading_offset); // virtual: the derived reset runs
+}
+
+bool Environment::isEnterPressed() const
+{
+    return false; // no terminal polling in the headless build
+}
+
+void Environment::saveImage(const std::string &filename) const
+{
+    screen_grabber_->saveRenderTargetToFile(filename);
+}
