@@ -96,6 +96,9 @@ def main():
                     help="Environment steps advanced by one kernel launch (the action source is on the device)")
     ap.add_argument("--grid-cell", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the secondary one-launch-per-step and host-boundary loops (used under rocprofv3 so that the "
+                         "kernel trace holds only the timed region's launches)")
     args = ap.parse_args()
 
     import torch
@@ -136,11 +139,12 @@ def main():
             env.rollout_random(c, args.seed, agent_base, step0 + done)
             done += c
 
+    from openkitchen_amd import sharding
+
     def fence():
         env.sync()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier(device_ids=[local_rank])
+        sharding.barrier(device_ids=[local_rank])
 
     # ---- warm-up (untimed) ----
     run_steps(args.warmup, 0)
@@ -152,23 +156,32 @@ def main():
     env.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier(device_ids=[local_rank])
+    sharding.barrier(device_ids=[local_rank])
     kernel_ms, launches = env.get_timing()
     env.set_timing(False)
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed_max = float(el.item())
+    elapsed_max = sharding.max_over_ranks(elapsed, device="cuda")
 
     # ---- secondary figure: one launch per step (what a host-side policy between steps would see) ----
-    one_steps = min(args.steps, 500)
+    one_steps = 0 if args.headline_only else min(args.steps, 500)
     env.sync()
     t1 = time.perf_counter()
     for s in range(one_steps):
         env.rollout_random(1, args.seed, agent_base, args.warmup + args.steps + s)
     env.sync()
     one_elapsed = time.perf_counter() - t1
+
+    # ---- tertiary figure: the host boundary (actions uploaded, distances downloaded every step: PCIe inclusive) ----
+    pcie_steps = 0 if args.headline_only else min(args.steps, 200)
+    thr_h = np.full(N, 30.0, dtype=np.float32)
+    steer_h = np.zeros(N, dtype=np.float32)
+    dist_h = np.zeros((N, R), dtype=np.float32)
+    env.sync()
+    t2 = time.perf_counter()
+    for s in range(pcie_steps):
+        env.set_actions(thr_h, steer_h)
+        env.step(1)
+        env.get(ok.capi.F_DIST, dist_h)
+    pcie_elapsed = time.perf_counter() - t2
 
     state = env.snapshot()
     crashed_frac = float(state["crashed"].mean())
@@ -200,11 +213,13 @@ def main():
                        "global_agents": total_agents, "steps_per_launch": spl, "parallelism": "dp%d (agent shards, no collective)" % world,
                        "grid_cell": info["grid_cell"], "lds_bytes": info["lds_bytes"]},
             "rays_per_sec": value * R,
-            "value_one_launch_per_step": N * one_steps / one_elapsed,
+            "value_one_launch_per_step": (N * one_steps / one_elapsed) if one_steps else None,
+            "value_host_boundary_pcie_inclusive": (N * pcie_steps / pcie_elapsed) if pcie_steps else None,
             "crashed_fraction_at_end": crashed_frac,
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "okStepKernel", "algorithmic_bytes_per_agent_step": b_alg,
+                         "kernel": "okStepCoopKernel" if info["grid_in_lds"] and R <= 64 else "okStepKernel",
+                         "algorithmic_bytes_per_agent_step": b_alg,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": int(launches),
                          "kernel_only_agent_steps_per_sec": N * args.steps / (kernel_ms * 1e-3) if kernel_ms > 0 else None,
                          "note": "VALU/LDS-bound path: algorithmic HBM traffic is ~0.35 KB per agent-step (BASELINE.md section 5)"},

@@ -1,0 +1,80 @@
+"""N>1 path on CPU: two processes over gloo.  The shard engines are oracle-backed stand-ins (tests only); what is under
+test is the product's sharding logic (openkitchen_amd/sharding.py): global agent ids per rank, the fitness all-gather's
+layout, max-over-ranks timing -- and that a sharded population reproduces the unsharded one."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    import _oracle as O
+    from openkitchen_amd import sharding
+
+    class OracleShard:
+        """Test-only engine with the BatchedEnvironment methods ShardedPopulation uses."""
+        def __init__(self, n, agent_base):
+            self.t = O.Track("Austin")
+            fan = O.default_ray_fan(8)
+            self.env = O.OracleEnv(self.t.segments, n, 8, fan, (self.t.x, self.t.y, self.t.heading))
+        def init_bench_state(self, agent_base, mode): self.env.init_bench_state(agent_base, mode)
+        def rollout_random(self, n, seed, agent_base, step_base): self.env.rollout_random(n, seed, agent_base, step_base)
+        def sync(self): pass
+        def nearest_track_idx(self):
+            s = self.env.snapshot()
+            out = np.zeros(self.env.N, dtype=np.int32)
+            O.lib().oracle_nearest_track_idx(self.t.x, self.t.y, self.t.P, s["pos_x"], s["pos_y"], self.env.N, out)
+            return out
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    pop = sharding.ShardedPopulation(lambda n, base: OracleShard(n, base), agents_per_rank=12)
+    assert (pop.agent_base, pop.n) == (rank * 12, 12)
+    elapsed = pop.timed(lambda: pop.rollout(60, seed=99, steps_per_launch=25))
+    assert elapsed > 0
+    fit = pop.fitness()
+    assert fit.shape == (world, 12)
+    slow = sharding.max_over_ranks(1.0 + rank)
+    assert slow == float(world)
+    assert sharding.split_population(10, 3) == [(0, 4), (4, 3), (7, 3)]
+    if rank == 0:
+        np.save(%(out)r, fit.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gloo_population_matches_unsharded(oracle, tmp_path):
+    out = str(tmp_path / "fitness.npy")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "out": out})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                    "--master-port", str(free_port()), str(script)], check=True, env=env, timeout=600, cwd=ROOT)
+    fit = np.load(out)
+    # the same population, unsharded, through the oracle
+    t = oracle.Track("Austin")
+    env1 = oracle.OracleEnv(t.segments, 24, 8, oracle.default_ray_fan(8), (t.x, t.y, t.heading))
+    env1.init_bench_state(0, 0)
+    env1.rollout_random(60, 99, 0, 0)
+    s = env1.snapshot()
+    want = np.zeros(24, dtype=np.int32)
+    oracle.lib().oracle_nearest_track_idx(t.x, t.y, t.P, s["pos_x"], s["pos_y"], 24, want)
+    assert np.array_equal(fit.reshape(-1).astype(np.int32), want)
