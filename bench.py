@@ -194,6 +194,13 @@ def main():
         steps_per_launch_avg = args.steps / max(launches, 1)
         bytes_per_launch = b_alg * N * steps_per_launch_avg
         achieved_gbs = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        traffic = None
+        try:  # measured HBM bytes per launch from the committed PMC profile, if it matches this configuration
+            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+            if (tj["agents"], tj["rays"], tj["track"], tj["steps_per_launch"]) == (N, R, args.track, spl):
+                traffic = tj["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         result = {
             "metric": "agent-steps/sec",
             "value": value,
@@ -217,7 +224,9 @@ def main():
             "value_host_boundary_pcie_inclusive": (N * pcie_steps / pcie_elapsed) if pcie_steps else None,
             "crashed_fraction_at_end": crashed_frac,
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/hbm_traffic.json)",
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel": "okStepCoopKernel" if info["grid_in_lds"] and R <= 64 else "okStepKernel",
                          "algorithmic_bytes_per_agent_step": b_alg,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": int(launches),
