@@ -168,6 +168,34 @@ OKENV_API int okenv_init_bench_state(okenv_t h, uint32_t agent_base, int32_t mod
  * (host or device pointers), or for every agent's current position when qx == NULL (n ignored). */
 OKENV_API int okenv_nearest_track_idx(okenv_t h, const float *qx, const float *qy, int32_t n, int32_t *out);
 
+/* ---- EvolutionaryRacer on the device (BASELINE configs 3 and 4) --------- */
+
+/* genetic::Network() for every agent (EvolutionaryRacer/Network.hpp:99-107): (R+2) -> hidden -> 6, no biases, weights
+ * U[-1,1) from Philox keyed (seed; agent_base+i, weight) in place of the unseeded Eigen Random().  hidden <= 32
+ * (30 in the reference).  Needs 5 <= R <= 64.  Weights live on the device, okenv_policy_mlp_weights_per_agent()
+ * floats per agent in the padded layout of include/okenv_math.h. */
+OKENV_API int okenv_policy_mlp_create(okenv_t h, int32_t hidden, uint32_t seed, uint32_t agent_base);
+OKENV_API int32_t okenv_policy_mlp_weights_per_agent(okenv_t h);
+OKENV_API int okenv_policy_mlp_get_weights(okenv_t h, float *out);       /* host or device pointer */
+OKENV_API int okenv_policy_mlp_set_weights(okenv_t h, const float *in);  /* host or device pointer */
+/* n_steps x { GeneticAgent::updateAction for every agent (GeneticAgent.hpp:37-107, Network::infer Network.hpp:119-155)
+ * from the previous step's observation; Environment::step } -- the inner loop of genetic_learner_sim.cpp:76-95, fused
+ * into the step kernel.  Call okenv_step(h, 1) once after a reset for the initial observation (:75). */
+OKENV_API int okenv_rollout_policy(okenv_t h, int32_t n_steps);
+/* number of agents with crashed_ == false (the loop's all_done test, genetic_learner_sim.cpp:85-92) */
+OKENV_API int okenv_alive_count(okenv_t h, int32_t *out);
+/* Agent::reset of EVERY agent to one pose (genetic_learner_sim.cpp:65-70) */
+OKENV_API int okenv_reset_all(okenv_t h, float x, float y, float rot_deg);
+/* assignScores (EvolutionaryRacer/MiscUtils.hpp:64-71): score = nearest centre-line index as float, kept on the
+ * device for okenv_ga_select_mate; `out` (N floats, host or device) may be NULL. */
+OKENV_API int okenv_ga_scores(okenv_t h, float *out);
+/* chooseAndMateAgents (EvolutionaryRacer/Mating.hpp:108-166) with mate2AgentsSelective (:52-99): the 5 best agents
+ * (ties to the lower index) become parents; offspring 0 clones the best, offspring 1 is the best mated with itself,
+ * every other offspring draws two different parents proportionally to score; per weight 10 % mutation to U[-1,1),
+ * else the dominant parent's weight with probability 0.75.  Draws come from Philox keyed (seed; agent_base+offspring,
+ * weight, generation) instead of std::random_device.  parents_out (5 ints, host) may be NULL. */
+OKENV_API int okenv_ga_select_mate(okenv_t h, uint32_t seed, uint32_t generation, uint32_t agent_base, int32_t *parents_out);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 
 /* When enabled, every step/collide/rollout launch is bracketed by HIP events on the handle's stream. */

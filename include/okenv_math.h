@@ -162,4 +162,92 @@ OK_HD uint32_t ok_start_index(uint32_t agent, uint32_t P)
     return (uint32_t)(agent * 2654435761u) % P;
 }
 
+/* ---- EvolutionaryRacer policy ------------------------------- */
+
+/* Weight layout per agent (floats): w1[(R+2)][OK_MLP_HID_PAD] then w2[OK_MLP_HID_PAD][OK_MLP_OUT_PAD]; entries beyond
+ * the hidden width H (30 in the reference, EvolutionaryRacer/Network.hpp:92-95) and beyond the 6 outputs are zero. */
+#define OK_MLP_HID_PAD 32
+#define OK_MLP_OUT 6
+#define OK_MLP_OUT_PAD 8
+#define OK_MLP_WEIGHTS(R) (((R) + 2) * OK_MLP_HID_PAD + OK_MLP_HID_PAD * OK_MLP_OUT_PAD)
+
+/* genetic::normalizeAngleDeg (EvolutionaryRacer/Network.hpp:16-27): repeated +-360 in fp32, bit for bit; the loops
+ * are capped at 65536 turns each so that an infinite rot_ cannot hang a kernel (the reference would spin forever). */
+OK_HD float ok_normalize_angle_deg(float angle)
+{
+    for (int i = 0; i < 65536 && angle < 360.0f; ++i) angle += 360.0f;
+    for (int i = 0; i < 65536 && angle >= 360.0f; ++i) angle -= 360.0f;
+    return angle;
+}
+
+/* GeneticAgent::updateAction's decode (EvolutionaryRacer/GeneticAgent.hpp:45-54) from the six pre-activations z:
+ * sigmoid(z) > 0.5 is taken as z > 0 (they differ only for 0 < z < ~6e-8, where fp32 sigmoid rounds to exactly 0.5). */
+OK_HD void ok_ga_decode_action(const float z[OK_MLP_OUT], float *throttle, float *steer)
+{
+    float t = 0.0f, s = 0.0f;
+    t += (z[0] > 0.0f) ? 0.3f : 0.0f;
+    t += (z[1] > 0.0f) ? -0.3f : 0.0f;
+    s += (z[2] > 0.0f) ? 1.0f : 0.0f;
+    s += (z[3] > 0.0f) ? 4.0f : 0.0f;
+    s += (z[4] > 0.0f) ? -1.0f : 0.0f;
+    s += (z[5] > 0.0f) ? -4.0f : 0.0f;
+    *throttle = t;
+    *steer = s;
+}
+
+/* Deterministic stand-ins for the reference's unseeded generators (Eigen Random(), std::random_device):
+ * initial weight w of agent a:      U[-1,1) from Philox(counter = (a, w, 1, 0), key = (seed, "oken"))
+ * mating draws of offspring o, weight w in generation g: Philox(counter = (o, w, 2, g)) -> u_mutate, u_value, u_parent
+ * parent choice of offspring o in generation g:          Philox(counter = (o, try, 3, g)) */
+OK_HD float ok_ga_initial_weight(uint32_t seed, uint32_t agent, uint32_t w)
+{
+    const ok_u32x4 r = ok_philox4x32(agent, w, 1u, 0u, seed, 0x6F6B656Eu);
+    return ok_u01(r.v[0]) * 2.0f - 1.0f;
+}
+
+/* Parent choice (EvolutionaryRacer/Mating.hpp:128-152): offspring 0 clones the best, offspring 1 mates the best with
+ * itself, every other offspring draws two DIFFERENT parents with probability proportional to the parents' scores
+ * (std::discrete_distribution; uniform when every score is zero).  ps[] = scores of the K best agents, best first.
+ * Returns first | second << 8, bit 16 = exact clone. */
+OK_HD uint32_t ok_ga_pick_parent(const float *ps, int K, float u)
+{
+    float total = 0.0f;
+    for (int k = 0; k < K; ++k) total += (ps[k] > 0.0f ? ps[k] : 0.0f);
+    if (!(total > 0.0f)) {
+        const int k = (int)(u * (float)K);
+        return (uint32_t)(k < K ? k : K - 1);
+    }
+    const float x = u * total;
+    float acc = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        acc += (ps[k] > 0.0f ? ps[k] : 0.0f);
+        if (x < acc) return (uint32_t)k;
+    }
+    return (uint32_t)(K - 1);
+}
+
+OK_HD uint32_t ok_ga_parent_pair(const float *ps, int K, uint32_t seed, uint32_t offspring, uint32_t generation)
+{
+    if (offspring == 0u) return 0u | (0u << 8) | (1u << 16); /* clone of the best */
+    if (offspring == 1u || K < 2) return 0u | (0u << 8);     /* best mated with itself: mutations only */
+    const ok_u32x4 r0 = ok_philox4x32(offspring, 0u, 3u, generation, seed, 0x6F6B656Eu);
+    const uint32_t first = ok_ga_pick_parent(ps, K, ok_u01(r0.v[0]));
+    uint32_t second = first;
+    for (uint32_t attempt = 1u; attempt <= 16u && second == first; ++attempt) {
+        const ok_u32x4 r = ok_philox4x32(offspring, attempt, 3u, generation, seed, 0x6F6B656Eu);
+        second = ok_ga_pick_parent(ps, K, ok_u01(r.v[0]));
+    }
+    if (second == first) second = (first + 1u) % (uint32_t)K; /* all but impossible; keeps "two different parents" */
+    return first | (second << 8);
+}
+
+/* true for the real entries of the padded per-agent weight block (index i in [0, OK_MLP_WEIGHTS(R))) */
+OK_HD int ok_mlp_weight_is_real(uint32_t i, int R, int H)
+{
+    const uint32_t n1 = (uint32_t)((R + 2) * OK_MLP_HID_PAD);
+    if (i < n1) return (int)((i % OK_MLP_HID_PAD) < (uint32_t)H);
+    const uint32_t q = i - n1;
+    return (int)((q / OK_MLP_OUT_PAD) < (uint32_t)H && (q % OK_MLP_OUT_PAD) < OK_MLP_OUT);
+}
+
 #endif /* OKENV_MATH_H */

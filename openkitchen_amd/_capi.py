@@ -31,7 +31,9 @@ SYMBOLS = [
     "okenv_get_distances", "okenv_get_flags", "okenv_step", "okenv_collide", "okenv_rollout_random",
     "okenv_init_bench_state", "okenv_nearest_track_idx", "okenv_set_timing", "okenv_get_timing", "okenv_track_load",
     "okenv_track_free", "okenv_track_num_points", "okenv_track_num_segments", "okenv_track_get",
-    "okenv_track_segments", "okenv_debug_sincos", "okenv_debug_cast_rays",
+    "okenv_track_segments", "okenv_debug_sincos", "okenv_debug_cast_rays", "okenv_policy_mlp_create",
+    "okenv_policy_mlp_weights_per_agent", "okenv_policy_mlp_get_weights", "okenv_policy_mlp_set_weights",
+    "okenv_rollout_policy", "okenv_alive_count", "okenv_reset_all", "okenv_ga_scores", "okenv_ga_select_mate",
 ]
 
 
@@ -108,6 +110,15 @@ def load(build_if_missing=True):
     L.okenv_track_segments.argtypes = [vp, vp]
     L.okenv_debug_sincos.argtypes = [i32, vp, vp, vp, i32]
     L.okenv_debug_cast_rays.argtypes = [vp, vp, vp, vp, i32, vp]
+    L.okenv_policy_mlp_create.argtypes = [vp, i32, u32, u32]
+    L.okenv_policy_mlp_weights_per_agent.argtypes = [vp]
+    L.okenv_policy_mlp_get_weights.argtypes = [vp, vp]
+    L.okenv_policy_mlp_set_weights.argtypes = [vp, vp]
+    L.okenv_rollout_policy.argtypes = [vp, i32]
+    L.okenv_alive_count.argtypes = [vp, C.POINTER(i32)]
+    L.okenv_reset_all.argtypes = [vp, f32, f32, f32]
+    L.okenv_ga_scores.argtypes = [vp, vp]
+    L.okenv_ga_select_mate.argtypes = [vp, u32, u32, u32, vp]
     _lib = L
     return L
 

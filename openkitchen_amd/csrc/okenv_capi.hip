@@ -56,6 +56,10 @@ struct okenv
     OkDeviceState st{};
     std::vector<void *> allocations;
     int         block_threads{1024}, grid_blocks{1};
+    // EvolutionaryRacer state
+    int      mlp_hidden{0};
+    float   *d_mlp_w{nullptr}, *d_mlp_w_new{nullptr}, *d_score{nullptr}, *d_parent_score{nullptr};
+    int32_t *d_nearest{nullptr}, *d_parents{nullptr}, *d_alive{nullptr};
     bool        coop{false};        // workgroup-cooperative two-phase kernel (LDS form, one ray per lane)
     float       phase1_range{48.F}; // T1 of the cooperative kernel [px]
     std::string last_error;
@@ -170,6 +174,7 @@ OkStepParams baseParams(okenv *h)
     p.cy            = h->d_cy;
     p.chead         = h->d_chead;
     p.P             = h->P;
+    p.mlp_w         = h->d_mlp_w;
     return p;
 }
 
@@ -358,6 +363,12 @@ extern "C"
             per_block = 64;
         if (per_block > 1024)
             per_block = 1024;
+        if (const char *env_bt = std::getenv("OKENV_BLOCK_THREADS"))
+        { // tuning knob: smaller workgroups (two per CU when the LDS image allows)
+            const long bt = std::atol(env_bt);
+            if (bt >= 64 && bt <= 1024 && bt % 64 == 0 && bt % h->G == 0)
+                per_block = bt < per_block ? bt : per_block;
+        }
         h->block_threads = static_cast<int>(per_block);
         h->grid_blocks   = static_cast<int>((total_lanes + per_block - 1) / per_block);
         h->coop          = h->grid_mode == kGridLds && h->rays_per_lane == 1;
@@ -686,6 +697,146 @@ extern "C"
             OK_HIP(h, hipFreeAsync(dq, h->stream));
         OK_HIP(h, hipFreeAsync(dout, h->stream));
         OK_HIP(h, hipStreamSynchronize(h->stream));
+        return OKENV_OK;
+    }
+
+    // ---- EvolutionaryRacer ---------------------------------------------------------------------------------------
+
+    int okenv_policy_mlp_create(okenv_t h, int32_t hidden, uint32_t seed, uint32_t agent_base)
+    {
+        if (!h || hidden < 1 || hidden > OK_MLP_HID_PAD)
+            return fail(h, OKENV_ERR_INVALID, "okenv_policy_mlp_create: hidden width must be in [1, 32]");
+        if (h->rays_per_lane != 1 || h->G < 8)
+            return fail(h, OKENV_ERR_INVALID, "okenv_policy_mlp_create: the fused policy needs 5 <= rays <= 64");
+        OK_HIP(h, hipSetDevice(h->device));
+        const size_t total = static_cast<size_t>(h->N) * OK_MLP_WEIGHTS(h->R);
+        int          rc;
+        if (!h->d_mlp_w)
+        {
+            if ((rc = devAlloc(h, &h->d_mlp_w, total)) || (rc = devAlloc(h, &h->d_mlp_w_new, total)) ||
+                (rc = devAlloc(h, &h->d_score, static_cast<size_t>(h->N))) || (rc = devAlloc(h, &h->d_nearest, static_cast<size_t>(h->N))) ||
+                (rc = devAlloc(h, &h->d_parents, 16U)) || (rc = devAlloc(h, &h->d_parent_score, 16U)) || (rc = devAlloc(h, &h->d_alive, 4U)))
+                return rc;
+        }
+        h->mlp_hidden = hidden;
+        hipLaunchKernelGGL(okGaInitWeightsKernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, h->stream, h->d_mlp_w, h->N,
+                           h->R, hidden, seed, agent_base);
+        OK_HIP(h, hipGetLastError());
+        return OKENV_OK;
+    }
+
+    int32_t okenv_policy_mlp_weights_per_agent(okenv_t h)
+    {
+        return h ? OK_MLP_WEIGHTS(h->R) : 0;
+    }
+
+    int okenv_policy_mlp_get_weights(okenv_t h, float *out)
+    {
+        if (!h || !out || !h->d_mlp_w)
+            return fail(h, OKENV_ERR_STATE, "okenv_policy_mlp_get_weights: no policy");
+        int rc = copyAny(h, out, h->d_mlp_w, sizeof(float) * static_cast<size_t>(h->N) * OK_MLP_WEIGHTS(h->R));
+        if (rc != OKENV_OK)
+            return rc;
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        return OKENV_OK;
+    }
+
+    int okenv_policy_mlp_set_weights(okenv_t h, const float *in)
+    {
+        if (!h || !in || !h->d_mlp_w)
+            return fail(h, OKENV_ERR_STATE, "okenv_policy_mlp_set_weights: no policy");
+        int rc = copyAny(h, h->d_mlp_w, in, sizeof(float) * static_cast<size_t>(h->N) * OK_MLP_WEIGHTS(h->R));
+        if (rc != OKENV_OK)
+            return rc;
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        return OKENV_OK;
+    }
+
+    int okenv_rollout_policy(okenv_t h, int32_t n_steps)
+    {
+        if (!h || n_steps < 0)
+            return fail(h, OKENV_ERR_INVALID, "okenv_rollout_policy: bad argument");
+        if (!h->d_mlp_w)
+            return fail(h, OKENV_ERR_STATE, "okenv_rollout_policy: call okenv_policy_mlp_create first");
+        if (n_steps == 0)
+            return OKENV_OK;
+        OkStepParams p  = baseParams(h);
+        p.n_steps       = n_steps;
+        p.action_source = kActionsMlpPolicy;
+        return launchStep(h, p);
+    }
+
+    int okenv_alive_count(okenv_t h, int32_t *out)
+    {
+        if (!h || !out)
+            return fail(h, OKENV_ERR_INVALID, "okenv_alive_count: NULL argument");
+        OK_HIP(h, hipSetDevice(h->device));
+        int *d = h->d_alive;
+        if (!d)
+        {
+            int rc = devAlloc(h, &h->d_alive, 4U);
+            if (rc != OKENV_OK)
+                return rc;
+            d = h->d_alive;
+        }
+        OK_HIP(h, hipMemsetAsync(d, 0, sizeof(int), h->stream));
+        hipLaunchKernelGGL(okAliveCountKernel, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->st.crashed, h->N, d);
+        OK_HIP(h, hipGetLastError());
+        OK_HIP(h, hipMemcpyAsync(out, d, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        return OKENV_OK;
+    }
+
+    int okenv_reset_all(okenv_t h, float x, float y, float rot_deg)
+    {
+        if (!h)
+            return OKENV_ERR_INVALID;
+        OK_HIP(h, hipSetDevice(h->device));
+        hipLaunchKernelGGL(okResetAllKernel, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->st, x, y, rot_deg, h->N);
+        OK_HIP(h, hipGetLastError());
+        return OKENV_OK;
+    }
+
+    int okenv_ga_scores(okenv_t h, float *out)
+    {
+        if (!h)
+            return OKENV_ERR_INVALID;
+        if (!h->d_mlp_w || h->P <= 0)
+            return fail(h, OKENV_ERR_STATE, "okenv_ga_scores: needs okenv_policy_mlp_create and okenv_set_centerline");
+        OK_HIP(h, hipSetDevice(h->device));
+        hipLaunchKernelGGL(okNearestIdxKernel, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->d_cx, h->d_cy, h->P, h->st.pos_x,
+                           h->st.pos_y, h->N, h->d_nearest);
+        hipLaunchKernelGGL(okGaScoreKernel, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->d_nearest, h->d_score, h->N);
+        OK_HIP(h, hipGetLastError());
+        if (out)
+        {
+            int rc = copyAny(h, out, h->d_score, sizeof(float) * static_cast<size_t>(h->N));
+            if (rc != OKENV_OK)
+                return rc;
+            OK_HIP(h, hipStreamSynchronize(h->stream));
+        }
+        return OKENV_OK;
+    }
+
+    int okenv_ga_select_mate(okenv_t h, uint32_t seed, uint32_t generation, uint32_t agent_base, int32_t *parents_out)
+    {
+        if (!h)
+            return OKENV_ERR_INVALID;
+        if (!h->d_mlp_w)
+            return fail(h, OKENV_ERR_STATE, "okenv_ga_select_mate: call okenv_policy_mlp_create first");
+        OK_HIP(h, hipSetDevice(h->device));
+        const int    K     = h->N < 5 ? h->N : 5; // kNumParents (Mating.hpp:118)
+        const size_t total = static_cast<size_t>(h->N) * OK_MLP_WEIGHTS(h->R);
+        hipLaunchKernelGGL(okGaTopKernel, dim3(1), dim3(1024), 0, h->stream, h->d_score, h->N, h->d_parents, h->d_parent_score, K);
+        hipLaunchKernelGGL(okGaMateKernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, h->stream, h->d_mlp_w, h->d_mlp_w_new,
+                           h->d_parents, h->d_parent_score, K, h->N, h->R, h->mlp_hidden, seed, generation, agent_base);
+        OK_HIP(h, hipGetLastError());
+        std::swap(h->d_mlp_w, h->d_mlp_w_new);
+        if (parents_out)
+        {
+            OK_HIP(h, hipMemcpyAsync(parents_out, h->d_parents, sizeof(int32_t) * K, hipMemcpyDeviceToHost, h->stream));
+            OK_HIP(h, hipStreamSynchronize(h->stream));
+        }
         return OKENV_OK;
     }
 

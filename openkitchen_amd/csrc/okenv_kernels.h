@@ -49,6 +49,7 @@ enum OkActionSource : int
 {
     kActionsStored      = 0, // use thr/steer arrays as they are (set by the host between launches)
     kActionsPhiloxReset = 1, // bench recipe: per step reset crashed agents, draw U[0,100) x U[-5,5)
+    kActionsMlpPolicy   = 2, // EvolutionaryRacer: per step GeneticAgent::updateAction from the previous observation
 };
 
 struct OkStepParams
@@ -76,6 +77,8 @@ struct OkStepParams
     uint32_t seed, agent_base, step_base;
     const float *cx, *cy, *chead;
     int          P;
+    // EvolutionaryRacer policy weights, OK_MLP_WEIGHTS(R) floats per agent (layout in okenv_math.h)
+    const float *mlp_w;
 };
 
 enum OkGridMode : int
@@ -274,8 +277,15 @@ __device__ __forceinline__ void okAgentPreStep(const OkStepParams &p, OkAgentReg
 
 // Hit transform of one ray (CollisionChecker.cu:144-166): writes sensor_hits_ (robot frame) and its norm, returns the
 // squared norm for the crash test.
-__device__ __forceinline__ float
-okRayEpilogue(const OkDeviceState &st, const long k, const float hx, const float hy, const float ox, const float oy, const float sr, const float cr)
+__device__ __forceinline__ float okRayEpilogue(const OkDeviceState &st,
+                                               const long           k,
+                                               const float          hx,
+                                               const float          hy,
+                                               const float          ox,
+                                               const float          oy,
+                                               const float          sr,
+                                               const float          cr,
+                                               float               &dist_out)
 {
     const float xt = hx - ox;
     const float yt = hy - oy;
@@ -284,8 +294,71 @@ okRayEpilogue(const OkDeviceState &st, const long k, const float hx, const float
     const float n2 = rx * rx + ry * ry;
     st.rel_x[k]    = rx;
     st.rel_y[k]    = ry;
-    st.dist[k]     = __builtin_sqrtf(n2);
+    dist_out       = __builtin_sqrtf(n2);
+    st.dist[k]     = dist_out;
     return n2;
+}
+
+// GeneticAgent::updateAction (EvolutionaryRacer/GeneticAgent.hpp:37-107) with Network::infer
+// (EvolutionaryRacer/Network.hpp:119-155): inputs [speed/100, normalizeAngleDeg(rot)/360, |hit_r|/200 ...] ->
+// relu(x W1) -> (x W2) > 0 decode.  Runs inside the step kernel, before the move, from the previous step's
+// observation: input r lives in the lane that owns ray r and is broadcast with wave shuffles; hidden unit u is
+// accumulated by lane u % 32 of the agent's group in the fixed order j = 0..R+1, output k by lane k in the order
+// i = 0..31 (the oracle accumulates in the same orders; Eigen's own order is unpinned).
+// Must be called by every lane of the group.  kUnits = hidden units per owning lane = 32 / min(G, 32).
+template <int kUnits>
+__device__ __forceinline__ void
+okMlpAction(const OkStepParams &p, const int a, const int rlane, const int G, OkAgentRegs &ag, const float dist_self, const bool ray_ok)
+{
+    const float *w1  = p.mlp_w + static_cast<size_t>(a) * OK_MLP_WEIGHTS(p.R);
+    const float *w2  = w1 + (p.R + 2) * OK_MLP_HID_PAD;
+    const float  x0  = ag.speed / 100.0F;
+    const float  x1  = ok_normalize_angle_deg(ag.rot) / 360.0F;
+    const float  xs  = ray_ok ? dist_self / 200.0F : 0.F;
+    const int    own = OK_MLP_HID_PAD / kUnits; // lanes of the group that own hidden units (= min(G, 32))
+    const int    ul  = rlane < own ? rlane : own - 1;
+    float        h[kUnits];
+#pragma unroll
+    for (int u = 0; u < kUnits; ++u)
+    {
+        const int unit = ul + u * own;
+        float     acc  = 0.F;
+        acc            = acc + x0 * w1[0 * OK_MLP_HID_PAD + unit];
+        acc            = acc + x1 * w1[1 * OK_MLP_HID_PAD + unit];
+        for (int j = 0; j < p.R; ++j)
+            acc = acc + __shfl(xs, j, G) * w1[(2 + j) * OK_MLP_HID_PAD + unit];
+        h[u] = (acc > 0.F) ? acc : 0.F;
+    }
+    const int kl = rlane < OK_MLP_OUT_PAD ? rlane : OK_MLP_OUT_PAD - 1;
+    float     z  = 0.F;
+#pragma unroll
+    for (int u = 0; u < kUnits; ++u)
+    {
+        for (int l = 0; l < own; ++l)
+        {
+            const int   i  = l + u * own; // hidden unit index, visited in increasing order
+            const float hv = __shfl(h[u], l, G);
+            z              = z + hv * w2[i * OK_MLP_OUT_PAD + kl];
+        }
+    }
+    float zs[OK_MLP_OUT];
+#pragma unroll
+    for (int k = 0; k < OK_MLP_OUT; ++k)
+        zs[k] = __shfl(z, k, G);
+    ok_ga_decode_action(zs, &ag.thr, &ag.steer);
+}
+
+__device__ __forceinline__ void
+okPolicyAction(const OkStepParams &p, const int a, const int rlane, const int G, OkAgentRegs &ag, const float dist_self, const bool ray_ok)
+{
+    if (p.action_source != kActionsMlpPolicy)
+        return;
+    if (G >= 32)
+        okMlpAction<1>(p, a, rlane, G, ag, dist_self, ray_ok);
+    else if (G == 16)
+        okMlpAction<2>(p, a, rlane, G, ag, dist_self, ray_ok);
+    else
+        okMlpAction<4>(p, a, rlane, G, ag, dist_self, ray_ok); // G == 8 (the C ABI refuses narrower fans)
 }
 
 template <int kMode>
@@ -320,9 +393,13 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
     const bool agent_ok = agent < p.N;
     const int  a        = agent_ok ? agent : 0;
     OkAgentRegs ag      = okLoadAgent(p.st, a);
+    // the policy reads the previous observation of this lane's ray (one ray per lane whenever a policy is attached)
+    const bool pol_ray = agent_ok && (rlane < p.R);
+    float      last_dist = (p.action_source == kActionsMlpPolicy && pol_ray) ? p.st.dist[static_cast<long>(a) * p.R + rlane] : 0.F;
 
     for (int s = 0; s < p.n_steps; ++s)
     {
+        okPolicyAction(p, a, rlane, G, ag, last_dist, pol_ray);
         okAgentPreStep(p, ag, a, s);
         // ---- collision pass (CollisionChecker.cu:113-174) ------------------------------------------------
         float sr, cr;
@@ -354,7 +431,7 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
                     hx = p.st.hit_x[k];
                     hy = p.st.hit_y[k];
                 }
-                const float n2 = okRayEpilogue(p.st, k, hx, hy, ox, oy, sr, cr);
+                const float n2 = okRayEpilogue(p.st, k, hx, hy, ox, oy, sr, cr, last_dist);
                 if (n2 < min_d2)
                     min_d2 = n2;
             }
@@ -411,6 +488,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
     const long k        = static_cast<long>(a) * p.R + (ray_ok ? r : 0);
     const float ray_deg = p.ray_deg[ray_ok ? r : 0];
     OkAgentRegs ag      = okLoadAgent(p.st, a);
+    float       last_dist = (p.action_source == kActionsMlpPolicy && ray_ok) ? p.st.dist[k] : 0.F;
 
 #if defined(OKENV_STAMPS)
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
@@ -428,6 +506,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
     for (int s = 0; s < p.n_steps; ++s)
     {
         const int par = s & 1;
+        okPolicyAction(p, a, r, G, ag, last_dist, ray_ok);
         okAgentPreStep(p, ag, a, s);
         float sr, cr;
         ok_sincosf(OK_DEG2RAD * ag.rot, &sr, &cr);
@@ -505,7 +584,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
                 hx = p.st.hit_x[k];
                 hy = p.st.hit_y[k];
             }
-            min_d2 = okRayEpilogue(p.st, k, hx, hy, ox, oy, sr, cr);
+            min_d2 = okRayEpilogue(p.st, k, hx, hy, ox, oy, sr, cr, last_dist);
             min_d2 = (min_d2 < OK_SENSOR_RANGE * OK_SENSOR_RANGE) ? min_d2 : OK_SENSOR_RANGE * OK_SENSOR_RANGE;
         }
         min_d2 = okGroupMin(min_d2, G);
@@ -540,6 +619,23 @@ __global__ void okResetKernel(OkDeviceState st, const int32_t *idx, const float 
     st.pos_x[a]     = x[i];
     st.pos_y[a]     = y[i];
     st.rot[a]       = rot[i];
+    st.acc[a]       = 0.F;
+    st.speed[a]     = 0.F;
+    st.crashed[a]   = 0;
+    st.timed_out[a] = 0;
+    st.thr[a]       = 0.F;
+    st.steer[a]     = 0.F;
+}
+
+// Agent::reset of every agent to one pose (genetic_learner_sim.cpp:65-70)
+__global__ void okResetAllKernel(OkDeviceState st, float x, float y, float rot, int N)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= N)
+        return;
+    st.pos_x[a]     = x;
+    st.pos_y[a]     = y;
+    st.rot[a]       = rot;
     st.acc[a]       = 0.F;
     st.speed[a]     = 0.F;
     st.crashed[a]   = 0;
@@ -609,6 +705,123 @@ __global__ void okNearestIdxKernel(const float *cx, const float *cy, int P, cons
     }
     if (i < n)
         out[i] = arg;
+}
+
+// ---- EvolutionaryRacer generation kernels ---------------------------------------
+
+// Network() random initialisation (Network.hpp:105-106): U[-1,1) per real weight, zero in the padding.
+__global__ void okGaInitWeightsKernel(float *w, int N, int R, int H, uint32_t seed, uint32_t agent_base)
+{
+    const int  per = OK_MLP_WEIGHTS(R);
+    const long t   = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= static_cast<long>(N) * per)
+        return;
+    const int  a    = static_cast<int>(t / per), i = static_cast<int>(t % per);
+    const bool real = ok_mlp_weight_is_real(static_cast<uint32_t>(i), R, H) != 0;
+    w[t] = real ? ok_ga_initial_weight(seed, agent_base + static_cast<uint32_t>(a), static_cast<uint32_t>(i)) : 0.F;
+}
+
+// assignScores (MiscUtils.hpp:64-71) keeps the nearest index as a float; alive counter for the rollout's end test.
+__global__ void okGaScoreKernel(const int32_t *nearest, float *score, int N)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N)
+        score[i] = static_cast<float>(nearest[i]);
+}
+
+__global__ void okAliveCountKernel(const uint8_t *crashed, int N, int *out)
+{
+    const int i     = blockIdx.x * blockDim.x + threadIdx.x;
+    const int alive = (i < N && crashed[i] == 0) ? 1 : 0;
+    const unsigned long long m = __ballot(alive);
+    if ((threadIdx.x & 63) == 0 && m)
+        atomicAdd(out, __popcll(m));
+}
+
+// The kNumParents = 5 best agents (Mating.hpp:115-119): descending score, ties to the lower index.  One workgroup.
+__global__ void __launch_bounds__(1024) okGaTopKernel(const float *score, int N, int32_t *parents, float *parent_score, int K)
+{
+    __shared__ float sv[1024];
+    __shared__ int   si[1024];
+    __shared__ int   chosen[16];
+    for (int k = 0; k < K; ++k)
+    {
+        float best = -__builtin_huge_valf();
+        int   arg  = 0x7FFFFFFF;
+        for (int i = threadIdx.x; i < N; i += blockDim.x)
+        {
+            bool taken = false;
+            for (int q = 0; q < k; ++q)
+                taken |= (chosen[q] == i);
+            const float v = score[i];
+            if (!taken && (v > best || (v == best && i < arg)))
+            {
+                best = v;
+                arg  = i;
+            }
+        }
+        sv[threadIdx.x] = best;
+        si[threadIdx.x] = arg;
+        __syncthreads();
+        for (int off = blockDim.x / 2; off > 0; off >>= 1)
+        {
+            if (static_cast<int>(threadIdx.x) < off)
+            {
+                const float ov = sv[threadIdx.x + off];
+                const int   oi = si[threadIdx.x + off];
+                if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x]))
+                {
+                    sv[threadIdx.x] = ov;
+                    si[threadIdx.x] = oi;
+                }
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0)
+        {
+            chosen[k]       = si[0];
+            parents[k]      = si[0];
+            parent_score[k] = sv[0];
+        }
+        __syncthreads();
+    }
+}
+
+// Parent pair of every offspring (Mating.hpp:128-152): offspring 0 clones the best, offspring 1 mates the best with
+// itself, the rest draw two DIFFERENT parents with probability proportional to the parents' scores
+// (std::discrete_distribution; uniform if all scores are zero).  pair[o] = first | second << 8, clone flag in bit 16.
+// mate2AgentsSelective (Mating.hpp:52-99) for every weight of every offspring: 10 % mutation to U[-1,1), otherwise the
+// dominant (higher score; the second on ties) parent's weight with probability 0.75, else the other's.
+__global__ void okGaMateKernel(const float *w_old, float *w_new, const int32_t *parents, const float *parent_score, int K, int N, int R,
+                               int H, uint32_t seed, uint32_t generation, uint32_t agent_base)
+{
+    const int  per = OK_MLP_WEIGHTS(R);
+    const long t   = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= static_cast<long>(N) * per)
+        return;
+    const uint32_t o = static_cast<uint32_t>(t / per), i = static_cast<uint32_t>(t % per);
+    float          ps[16];
+    for (int k = 0; k < K; ++k)
+        ps[k] = parent_score[k];
+    const uint32_t og     = agent_base + o; // global offspring id keeps sharded islands' streams distinct
+    const uint32_t pair   = ok_ga_parent_pair(ps, K, seed, og, generation);
+    const uint32_t first  = pair & 0xFFU, second = (pair >> 8) & 0xFFU;
+    const bool     clone  = (pair >> 16) & 1U;
+    const uint32_t dom    = (ps[first] > ps[second]) ? first : second;
+    const uint32_t sub    = (ps[first] > ps[second]) ? second : first;
+    const float    wd     = w_old[static_cast<long>(parents[dom]) * per + i];
+    const float    wsub   = w_old[static_cast<long>(parents[sub]) * per + i];
+    const bool     real   = ok_mlp_weight_is_real(i, R, H) != 0;
+    float          out    = wd;
+    if (real && !clone)
+    {
+        const ok_u32x4 r = ok_philox4x32(og, i, 2U, generation, seed, 0x6F6B656EU);
+        if (ok_u01(r.v[0]) < 0.1F)
+            out = (ok_u01(r.v[1]) - 0.5F) * 2.F;
+        else
+            out = (ok_u01(r.v[2]) < 0.75F) ? wd : wsub;
+    }
+    w_new[t] = real ? out : 0.F;
 }
 
 __global__ void okDebugSincosKernel(const float *x, float *s, float *c, int n)

@@ -179,6 +179,43 @@ class BatchedEnvironment:
         capi.check(self._L.okenv_nearest_track_idx(self._h, capi.ptr(qx), capi.ptr(qy), qx.size, capi.ptr(out)), self._h)
         return out
 
+    # ---- EvolutionaryRacer on the device (include/okenv.h) -------------------------------------------------
+    def policy_mlp_create(self, hidden=30, seed=1234, agent_base=0):
+        capi.check(self._L.okenv_policy_mlp_create(self._h, int(hidden), int(seed), int(agent_base)), self._h)
+        self.weights_per_agent = self._L.okenv_policy_mlp_weights_per_agent(self._h)
+
+    def policy_weights(self):
+        out = np.zeros((self.N, self.weights_per_agent), dtype=np.float32)
+        capi.check(self._L.okenv_policy_mlp_get_weights(self._h, capi.ptr(out)), self._h)
+        return out
+
+    def set_policy_weights(self, w):
+        if isinstance(w, np.ndarray):
+            w = np.ascontiguousarray(w, dtype=np.float32)
+        capi.check(self._L.okenv_policy_mlp_set_weights(self._h, capi.ptr(w)), self._h)
+
+    def rollout_policy(self, n_steps):
+        capi.check(self._L.okenv_rollout_policy(self._h, int(n_steps)), self._h)
+
+    def alive_count(self):
+        n = C.c_int32()
+        capi.check(self._L.okenv_alive_count(self._h, C.byref(n)), self._h)
+        return n.value
+
+    def reset_all(self, x, y, rot_deg):
+        capi.check(self._L.okenv_reset_all(self._h, float(x), float(y), float(rot_deg)), self._h)
+
+    def ga_scores(self, out=None):
+        if out is None:
+            out = np.zeros(self.N, dtype=np.float32)
+        capi.check(self._L.okenv_ga_scores(self._h, capi.ptr(out)), self._h)
+        return out
+
+    def ga_select_mate(self, seed, generation, agent_base=0):
+        parents = np.zeros(5, dtype=np.int32)
+        capi.check(self._L.okenv_ga_select_mate(self._h, int(seed), int(generation), int(agent_base), capi.ptr(parents)), self._h)
+        return parents
+
     # ---- measurement / self-checks ------------------------------------------------------------------
     def set_timing(self, enabled):
         capi.check(self._L.okenv_set_timing(self._h, 1 if enabled else 0), self._h)

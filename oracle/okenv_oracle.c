@@ -284,6 +284,9 @@ typedef struct oracle_env {
     /* centre line for resets / nearest index */
     int P;
     float *cx, *cy, *chead;
+    /* EvolutionaryRacer: per-agent MLP weights (padded layout of okenv_math.h), scores */
+    int mlp_hidden;
+    float *mlp_w, *score;
 } oracle_env;
 
 #define ALLOC(T, n) ((T *)calloc((size_t)(n), sizeof(T)))
@@ -315,6 +318,7 @@ ORACLE_API void oracle_env_destroy(oracle_env *e)
     free(e->disp_ctr); free(e->disp_x); free(e->disp_y); free(e->disp_to);
     free(e->hit_x); free(e->hit_y); free(e->rel_x); free(e->rel_y); free(e->dist);
     free(e->cx); free(e->cy); free(e->chead);
+    free(e->mlp_w); free(e->score);
     free(e);
 }
 
@@ -608,4 +612,136 @@ ORACLE_API float oracle_cast_ray(float ox, float oy, float angle_rad, const floa
             min_t = t;
     }
     return min_t;
+}
+
+/* ============================================================================================ */
+/* EvolutionaryRacer                                        */
+/* ============================================================================================ */
+
+/* genetic::Network() (EvolutionaryRacer/Network.hpp:99-107), weights from the Philox stand-in of okenv_math.h */
+ORACLE_API void oracle_ga_create(oracle_env *e, int hidden, uint32_t seed, uint32_t agent_base)
+{
+    const int per = OK_MLP_WEIGHTS(e->R);
+    free(e->mlp_w); free(e->score);
+    e->mlp_hidden = hidden;
+    e->mlp_w = ALLOC(float, (size_t)e->N * per);
+    e->score = ALLOC(float, e->N);
+    for (int a = 0; a < e->N; ++a)
+        for (int i = 0; i < per; ++i)
+            e->mlp_w[(size_t)a * per + i] =
+                ok_mlp_weight_is_real((uint32_t)i, e->R, hidden) ? ok_ga_initial_weight(seed, agent_base + (uint32_t)a, (uint32_t)i) : 0.0f;
+}
+
+ORACLE_API int oracle_ga_weights_per_agent(const oracle_env *e) { return OK_MLP_WEIGHTS(e->R); }
+ORACLE_API void oracle_ga_get_weights(const oracle_env *e, float *out)
+{
+    memcpy(out, e->mlp_w, sizeof(float) * (size_t)e->N * OK_MLP_WEIGHTS(e->R));
+}
+ORACLE_API void oracle_ga_set_weights(oracle_env *e, const float *in)
+{
+    memcpy(e->mlp_w, in, sizeof(float) * (size_t)e->N * OK_MLP_WEIGHTS(e->R));
+}
+
+/* GeneticAgent::updateAction (GeneticAgent.hpp:37-107) + Network::infer (Network.hpp:119-155).  Accumulation orders:
+ * hidden unit u over inputs j = 0..R+1, output k over hidden units i = 0..31 (zero-padded beyond the hidden width). */
+static void ga_update_action(oracle_env *e, int a)
+{
+    const int R = e->R;
+    const float *w1 = e->mlp_w + (size_t)a * OK_MLP_WEIGHTS(R);
+    const float *w2 = w1 + (R + 2) * OK_MLP_HID_PAD;
+    float h[OK_MLP_HID_PAD], z[OK_MLP_OUT];
+    const float x0 = e->speed[a] / 100.0f;
+    const float x1 = ok_normalize_angle_deg(e->rot[a]) / 360.0f;
+    for (int u = 0; u < OK_MLP_HID_PAD; ++u) {
+        float acc = 0.0f;
+        acc = acc + x0 * w1[0 * OK_MLP_HID_PAD + u];
+        acc = acc + x1 * w1[1 * OK_MLP_HID_PAD + u];
+        for (int j = 0; j < R; ++j) {
+            const float xj = e->dist[(size_t)a * R + j] / 200.0f;
+            acc = acc + xj * w1[(2 + j) * OK_MLP_HID_PAD + u];
+        }
+        h[u] = (acc > 0.0f) ? acc : 0.0f;
+    }
+    for (int k = 0; k < OK_MLP_OUT; ++k) {
+        float acc = 0.0f;
+        for (int i = 0; i < OK_MLP_HID_PAD; ++i) acc = acc + h[i] * w2[i * OK_MLP_OUT_PAD + k];
+        z[k] = acc;
+    }
+    ok_ga_decode_action(z, &e->thr[a], &e->steer[a]);
+}
+
+/* genetic_learner_sim.cpp:76-95: n x { updateAction for all; env.step() } */
+ORACLE_API void oracle_env_rollout_policy(oracle_env *e, int n_steps)
+{
+    for (int s = 0; s < n_steps; ++s) {
+        for (int a = 0; a < e->N; ++a) ga_update_action(e, a);
+        step_range(e, 0, e->N);
+    }
+}
+
+ORACLE_API int oracle_env_alive_count(const oracle_env *e)
+{
+    int n = 0;
+    for (int a = 0; a < e->N; ++a) n += e->crashed[a] ? 0 : 1;
+    return n;
+}
+
+ORACLE_API void oracle_env_reset_all(oracle_env *e, float x, float y, float rot)
+{
+    for (int a = 0; a < e->N; ++a) agent_reset(e, a, x, y, rot);
+}
+
+/* assignScores (MiscUtils.hpp:64-71) */
+ORACLE_API void oracle_ga_scores(oracle_env *e, float *out)
+{
+    for (int a = 0; a < e->N; ++a) {
+        float best = FLT_MAX; int bi = 0;
+        for (int i = 0; i < e->P; ++i) {
+            const float dx = e->pos_x[a] - e->cx[i], dy = e->pos_y[a] - e->cy[i];
+            const float d = dx * dx + dy * dy;
+            if (d < best) { best = d; bi = i; }
+        }
+        e->score[a] = (float)bi;
+        if (out) out[a] = e->score[a];
+    }
+}
+
+/* chooseAndMateAgents (Mating.hpp:108-166) + mate2AgentsSelective (:52-99) with the Philox stand-ins */
+ORACLE_API void oracle_ga_select_mate(oracle_env *e, uint32_t seed, uint32_t generation, uint32_t agent_base, int32_t *parents_out)
+{
+    const int N = e->N, per = OK_MLP_WEIGHTS(e->R), K = N < 5 ? N : 5;
+    int parents[5]; float ps[5];
+    for (int k = 0; k < K; ++k) { /* descending score, ties to the lower index */
+        float best = -HUGE_VALF; int arg = -1;
+        for (int a = 0; a < N; ++a) {
+            int taken = 0;
+            for (int q = 0; q < k; ++q) taken |= (parents[q] == a);
+            if (!taken && (arg < 0 || e->score[a] > best)) { best = e->score[a]; arg = a; }
+        }
+        parents[k] = arg; ps[k] = best;
+        if (parents_out) parents_out[k] = arg;
+    }
+    float *nw = ALLOC(float, (size_t)N * per);
+    for (int o = 0; o < N; ++o) {
+        const uint32_t og = agent_base + (uint32_t)o;
+        const uint32_t pair = ok_ga_parent_pair(ps, K, seed, og, generation);
+        const uint32_t first = pair & 0xFFu, second = (pair >> 8) & 0xFFu;
+        const int clone = (int)((pair >> 16) & 1u);
+        const uint32_t dom = (ps[first] > ps[second]) ? first : second; /* n1 = agent_2 on ties (Mating.hpp:59) */
+        const uint32_t sub = (ps[first] > ps[second]) ? second : first;
+        const float *wd = e->mlp_w + (size_t)parents[dom] * per;
+        const float *ws = e->mlp_w + (size_t)parents[sub] * per;
+        for (int i = 0; i < per; ++i) {
+            float out = wd[i];
+            const int real = ok_mlp_weight_is_real((uint32_t)i, e->R, e->mlp_hidden);
+            if (real && !clone) {
+                const ok_u32x4 r = ok_philox4x32(og, (uint32_t)i, 2u, generation, seed, 0x6F6B656Eu);
+                if (ok_u01(r.v[0]) < 0.1f) out = (ok_u01(r.v[1]) - 0.5f) * 2.0f;
+                else out = (ok_u01(r.v[2]) < 0.75f) ? wd[i] : ws[i];
+            }
+            nw[(size_t)o * per + i] = real ? out : 0.0f;
+        }
+    }
+    free(e->mlp_w);
+    e->mlp_w = nw;
 }

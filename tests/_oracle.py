@@ -72,6 +72,15 @@ def lib():
         L.oracle_cast_ray.argtypes = [C.c_float, C.c_float, C.c_float, f32p, C.c_int]
         L.oracle_philox.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                     C.POINTER(C.c_uint32)]
+        L.oracle_ga_create.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32]
+        L.oracle_ga_weights_per_agent.argtypes = [C.c_void_p]
+        L.oracle_ga_get_weights.argtypes = [C.c_void_p, f32p]
+        L.oracle_ga_set_weights.argtypes = [C.c_void_p, f32p]
+        L.oracle_env_rollout_policy.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_env_alive_count.argtypes = [C.c_void_p]
+        L.oracle_env_reset_all.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.oracle_ga_scores.argtypes = [C.c_void_p, f32p]
+        L.oracle_ga_select_mate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, i32p]
         _lib = L
     return _lib
 
@@ -198,3 +207,39 @@ class OracleEnv:
             lib().oracle_env_rollout_random_mt(self.h, n_steps, seed, agent_base, step_base, threads)
         else:
             lib().oracle_env_rollout_random(self.h, n_steps, seed, agent_base, step_base)
+
+
+class OracleGA:
+    """EvolutionaryRacer helpers on top of an OracleEnv (mirror of BatchedEnvironment's policy/GA methods)."""
+
+    def __init__(self, env, hidden=30, seed=1234, agent_base=0):
+        self.env = env
+        lib().oracle_ga_create(env.h, hidden, seed, agent_base)
+        self.per = lib().oracle_ga_weights_per_agent(env.h)
+
+    def weights(self):
+        w = np.zeros(self.env.N * self.per, dtype=np.float32)
+        lib().oracle_ga_get_weights(self.env.h, w)
+        return w.reshape(self.env.N, self.per)
+
+    def set_weights(self, w):
+        lib().oracle_ga_set_weights(self.env.h, np.ascontiguousarray(w, dtype=np.float32).reshape(-1))
+
+    def rollout_policy(self, n):
+        lib().oracle_env_rollout_policy(self.env.h, n)
+
+    def alive_count(self):
+        return lib().oracle_env_alive_count(self.env.h)
+
+    def reset_all(self, x, y, rot):
+        lib().oracle_env_reset_all(self.env.h, x, y, rot)
+
+    def scores(self):
+        out = np.zeros(self.env.N, dtype=np.float32)
+        lib().oracle_ga_scores(self.env.h, out)
+        return out
+
+    def select_mate(self, seed, generation, agent_base=0):
+        parents = np.zeros(5, dtype=np.int32)
+        lib().oracle_ga_select_mate(self.env.h, seed, generation, agent_base, parents)
+        return parents
