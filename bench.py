@@ -83,6 +83,51 @@ def cpu_baseline(track_name, R, seed, log):
     return out
 
 
+def bench_evolution(args, ok, torch, dist, rank, world, local_rank, log):
+    """BASELINE configs 3 and 4: full EvolutionaryRacer generations on the device, one island population per GPU."""
+    from openkitchen_amd import sharding
+    from openkitchen_amd.evolution import EvolutionaryRacer
+
+    track_name = "Monza" if args.config == "c3" else "Spa"
+    N, R = 8192, 32
+    track = ok.Track(track_name)
+    env = ok.BatchedEnvironment.from_track(track, N, R, device=local_rank)
+    ga = EvolutionaryRacer(env, track, hidden=30, seed=args.seed + rank, agent_base=rank * N, max_steps=4000,
+                           steps_per_launch=args.steps_per_launch, device="cuda")
+    ga.run_generation()  # warm-up generation (untimed)
+    env.sync()
+    torch.cuda.synchronize()
+    sharding.barrier(device_ids=[local_rank])
+    t0 = time.perf_counter()
+    recs = [ga.run_generation() for _ in range(args.generations)]
+    env.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    sharding.barrier(device_ids=[local_rank])
+    elapsed_max = sharding.max_over_ranks(elapsed, device="cuda")
+    steps = sum(r["steps"] for r in recs)
+    steps_t = torch.tensor([float(steps)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(steps_t)
+    if rank == 0:
+        total_agent_steps = N * float(steps_t.item())
+        print(json.dumps({
+            "metric": "agent-steps/sec", "value": total_agent_steps / elapsed_max, "unit": "agent-steps/s", "n_gpus": world,
+            "steps": steps, "warmup": recs[0]["steps"], "ms_per_step": elapsed_max / max(steps, 1) * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: EvolutionaryRacer, %d agents x %d rays per GPU, %s.csv, fused 34-30-6 MLP policy + step, "
+                                   "rollout until all crashed (<= 4000 steps), score, select top-5, mate%s"
+                                   % (args.config.upper(), N, R, track_name, ", RCCL fitness all-gather per generation" if world > 1 else ""),
+                       "generations": args.generations, "parallelism": "dp%d island populations" % world},
+            "generation_wall_s": elapsed_max / args.generations,
+            "generations": [{k: r[k] for k in ("generation", "steps", "rollout_s", "select_mate_s", "island_best", "colony_best")} for r in recs],
+        }), flush=True)
+    env.close()
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +141,10 @@ def main():
                     help="Environment steps advanced by one kernel launch (the action source is on the device)")
     ap.add_argument("--grid-cell", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"],
+                    help="c2: headline (random actions); c3/c4: EvolutionaryRacer generations (population 8192 x 32 rays per GPU, "
+                         "Monza / Spa, fused MLP policy, score, select, mate; c4 adds the per-generation RCCL fitness all-gather)")
+    ap.add_argument("--generations", type=int, default=5)
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the secondary one-launch-per-step and host-boundary loops (used under rocprofv3 so that the "
                          "kernel trace holds only the timed region's launches)")
@@ -123,6 +172,8 @@ def main():
     import openkitchen_amd as ok
 
     ok.build()
+    if args.config in ("c3", "c4"):
+        return bench_evolution(args, ok, torch, dist, rank, world, local_rank, log)
     track = ok.Track(args.track)
     N, R = args.agents, args.rays
     env = ok.BatchedEnvironment.from_track(track, N, R, device=local_rank, grid_cell=args.grid_cell)

@@ -1,0 +1,60 @@
+"""Host-side driver of the EvolutionaryRacer generation loop (reference EvolutionaryRacer/genetic_learner_sim.cpp:47-96)
+over the device-resident population: every step of the loop body runs on the GPU (policy + Environment::step fused in
+one kernel, scores, selection, mating); the host only decides when a rollout is over.
+
+With torch.distributed initialised, every rank runs an independent island population on its own GPU (BASELINE config 4)
+and the per-generation fitness vectors are all-gathered over RCCL for the colony statistics; selection and mating stay
+local to each island, as SURVEY.md section 8e prescribes.
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import sharding
+from . import _capi as capi
+
+
+class EvolutionaryRacer:
+    def __init__(self, env, track, hidden=30, seed=1234, agent_base=0, max_steps=4000, steps_per_launch=100, device=None):
+        self.env, self.track = env, track
+        self.seed, self.agent_base = int(seed), int(agent_base)
+        self.max_steps, self.spl = int(max_steps), int(steps_per_launch)
+        self.device = device
+        self.generation = 0
+        env.set(capi.F_MODE, np.full(env.N, capi.MODE_ACCELERATION, dtype=np.uint8))  # GeneticAgent.hpp:28,34
+        env.policy_mlp_create(hidden, seed, agent_base)
+        self.start = (float(track.x[3]), float(track.y[3]), float(track.heading[0]))  # genetic_learner_sim.cpp:34-36
+        self.history = []
+
+    def rollout(self):
+        """Reset everybody to the start line and drive until every agent has crashed or timed out."""
+        e = self.env
+        e.reset_all(*self.start)
+        e.step(1)  # initial observation (genetic_learner_sim.cpp:75)
+        steps = 1
+        while steps < self.max_steps:
+            n = min(self.spl, self.max_steps - steps)
+            e.rollout_policy(n)
+            steps += n
+            if e.alive_count() == 0:
+                break
+        return steps
+
+    def run_generation(self):
+        t0 = time.perf_counter()
+        steps = self.rollout()
+        t1 = time.perf_counter()
+        scores = self.env.ga_scores()  # assignScores
+        local = torch.as_tensor(scores, dtype=torch.float32, device=self.device if self.device is not None else "cpu")
+        colony = sharding.all_gather_fitness(local)  # [world, N]: global colony statistics (showColonyScore)
+        parents = self.env.ga_select_mate(self.seed, self.generation, self.agent_base)  # chooseAndMateAgents
+        self.env.sync()
+        t2 = time.perf_counter()
+        rec = {"generation": self.generation, "steps": steps, "rollout_s": t1 - t0, "select_mate_s": t2 - t1,
+               "island_best": float(scores.max()), "island_mean": float(scores.mean()),
+               "colony_best": float(colony.max().item()), "colony_mean": float(colony.mean().item()),
+               "parents": parents.tolist()}
+        self.history.append(rec)
+        self.generation += 1
+        return rec
