@@ -196,6 +196,25 @@ OKENV_API int okenv_ga_scores(okenv_t h, float *out);
  * weight, generation) instead of std::random_device.  parents_out (5 ints, host) may be NULL. */
 OKENV_API int okenv_ga_select_mate(okenv_t h, uint32_t seed, uint32_t generation, uint32_t agent_base, int32_t *parents_out);
 
+/* ---- RLRacers/Q_Learning on the device (BASELINE config 5) ----------------------- */
+
+/* One 243 x 3 table per agent, every entry numeric_limits<float>::lowest() (RLRacers/Q_Learning/QAgent.hpp:31-36,64-68).
+ * The state uses five rays; with a fan of more than five rays the ones nearest to -70, -30, 0, +30, +70 degrees are taken
+ * (ties to the lower index) -- the reference fan is exactly those five (QAgent.hpp:56-62).  Needs R >= 5 and the LDS form. */
+OKENV_API int okenv_q_create(okenv_t h);
+/* Start of an episode (q_racer_sim.cpp:129-154): every agent reset onto centre-line point `reset_idx` with the track
+ * heading, prev_track_idx = that point's nearest index, one Environment::step for the initial observation, current
+ * state = discretizeState().  All agents must be in VELOCITY mode (the action map sets the speed). */
+OKENV_API int okenv_q_begin_episode(okenv_t h, int32_t reset_idx);
+/* n_steps x { updateAction (epsilon-greedy, QAgent.hpp:98-119); Environment::step; discretizeState; reward
+ * (QAgent.hpp:150-168, nearest centre-line index); learn (QAgent.hpp:121-138) } for every agent, crashed ones included, as
+ * q_racer_sim.cpp:158-182 does.  Random draws: Philox keyed (seed; agent_base+i, step_base+s). */
+OKENV_API int okenv_rollout_q(okenv_t h, int32_t n_steps, float epsilon, uint32_t seed, uint32_t agent_base, uint32_t step_base);
+OKENV_API int okenv_q_get_table(okenv_t h, float *out);      /* [N][243][3], host or device pointer */
+OKENV_API int okenv_q_set_table(okenv_t h, const float *in);
+/* current_state_idx_, current_action_idx_, prev_track_idx_ per agent (host arrays, any may be NULL) */
+OKENV_API int okenv_q_get_state(okenv_t h, int32_t *state, int32_t *action, int32_t *prev_idx);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 
 /* When enabled, every step/collide/rollout launch is bracketed by HIP events on the handle's stream. */

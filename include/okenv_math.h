@@ -250,4 +250,63 @@ OK_HD int ok_mlp_weight_is_real(uint32_t i, int R, int H)
     return (int)((q / OK_MLP_OUT_PAD) < (uint32_t)H && (q % OK_MLP_OUT_PAD) < OK_MLP_OUT);
 }
 
+/* ---- RLRacers/Q_Learning ------------------------------------------------ */
+
+#define OK_Q_STATES 243 /* 5 rays x 3 proximity bins, QAgent.hpp:31-34 */
+#define OK_Q_ACTIONS 3
+#define OK_Q_INVALID (-3.40282346638528859811704183484516925e+38f) /* numeric_limits<float>::lowest(), QAgent.hpp:36 */
+
+/* QLearnAgent::discretizeState's bin of one ray (QAgent.hpp:72-94): < 5 -> 0, < 10 -> 1, else 2 */
+OK_HD int ok_q_bin(float ray_dist)
+{
+    return (ray_dist < 5.0f) ? 0 : ((ray_dist < 10.0f) ? 1 : 2);
+}
+
+/* index of the largest of three values, the first on ties (std::max_element, QAgent.hpp:108-110) */
+OK_HD int ok_q_argmax3(float q0, float q1, float q2)
+{
+    int idx = 0;
+    float m = q0;
+    if (q1 > m) { m = q1; idx = 1; }
+    if (q2 > m) { idx = 2; }
+    return idx;
+}
+
+/* Epsilon-greedy draw (QAgent.hpp:98-119) with Philox(counter = (agent, step, 4, 0)) standing in for raylib's
+ * GetRandomValue: explore iff u0 < epsilon, random action = min(2, floor(3 u1)). */
+OK_HD int ok_q_choose_action(uint32_t seed, uint32_t agent, uint32_t step, float epsilon, float q0, float q1, float q2)
+{
+    const ok_u32x4 r = ok_philox4x32(agent, step, 4u, 0u, seed, 0x6F6B656Eu);
+    if (ok_u01(r.v[0]) < epsilon) {
+        const int a = (int)(ok_u01(r.v[1]) * 3.0f);
+        return a > 2 ? 2 : a;
+    }
+    return ok_q_argmax3(q0, q1, q2);
+}
+
+/* kActionMap (QAgent.hpp:40-42): 0 -> (60, 0), 1 -> (30, +5), 2 -> (30, -5) */
+OK_HD void ok_q_action_values(int action, float *throttle, float *steer)
+{
+    *throttle = (action == 0) ? 60.0f : 30.0f;
+    *steer = (action == 0) ? 0.0f : ((action == 1) ? 5.0f : -5.0f);
+}
+
+/* QLearnAgent::reward (QAgent.hpp:150-168); *prev_idx is updated only when the agent has not crashed */
+OK_HD float ok_q_reward(int crashed, int nearest_idx, int *prev_idx, int track_len)
+{
+    if (crashed) return -200.0f;
+    int progression = nearest_idx - *prev_idx;
+    *prev_idx = nearest_idx;
+    if (progression < 0) progression = -progression;
+    return (float)((progression > track_len / 2) ? track_len - progression : progression);
+}
+
+/* QLearnAgent::learn (QAgent.hpp:121-138): returns the new Q(s, a) */
+OK_HD float ok_q_learn(float old_q, float max_q_next, float reward)
+{
+    const float target = reward + 0.8f * max_q_next;
+    if (old_q == OK_Q_INVALID || max_q_next == OK_Q_INVALID) return reward;
+    return old_q + 0.2f * (target - old_q);
+}
+
 #endif /* OKENV_MATH_H */

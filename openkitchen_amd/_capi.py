@@ -34,6 +34,7 @@ SYMBOLS = [
     "okenv_track_segments", "okenv_debug_sincos", "okenv_debug_cast_rays", "okenv_policy_mlp_create",
     "okenv_policy_mlp_weights_per_agent", "okenv_policy_mlp_get_weights", "okenv_policy_mlp_set_weights",
     "okenv_rollout_policy", "okenv_alive_count", "okenv_reset_all", "okenv_ga_scores", "okenv_ga_select_mate",
+    "okenv_q_create", "okenv_q_begin_episode", "okenv_rollout_q", "okenv_q_get_table", "okenv_q_set_table", "okenv_q_get_state",
 ]
 
 
@@ -119,6 +120,12 @@ def load(build_if_missing=True):
     L.okenv_reset_all.argtypes = [vp, f32, f32, f32]
     L.okenv_ga_scores.argtypes = [vp, vp]
     L.okenv_ga_select_mate.argtypes = [vp, u32, u32, u32, vp]
+    L.okenv_q_create.argtypes = [vp]
+    L.okenv_q_begin_episode.argtypes = [vp, i32]
+    L.okenv_rollout_q.argtypes = [vp, i32, f32, u32, u32, u32]
+    L.okenv_q_get_table.argtypes = [vp, vp]
+    L.okenv_q_set_table.argtypes = [vp, vp]
+    L.okenv_q_get_state.argtypes = [vp, vp, vp, vp]
     _lib = L
     return L
 

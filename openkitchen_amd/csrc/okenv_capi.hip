@@ -6,6 +6,7 @@
 // okenv_create fails with OKENV_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -60,6 +61,12 @@ struct okenv
     int      mlp_hidden{0};
     float   *d_mlp_w{nullptr}, *d_mlp_w_new{nullptr}, *d_score{nullptr}, *d_parent_score{nullptr};
     int32_t *d_nearest{nullptr}, *d_parents{nullptr}, *d_alive{nullptr};
+    // Q-learning state
+    float   *d_q_table{nullptr};
+    int32_t *d_q_state{nullptr}, *d_q_action{nullptr}, *d_q_prev{nullptr}, *d_q_reset_nearest{nullptr};
+    int      q_ray[5]{0, 0, 0, 0, 0};
+    float    q_epsilon{0.F};
+    std::vector<float> host_cx, host_cy, host_chead, host_ray_deg;
     bool        coop{false};        // workgroup-cooperative two-phase kernel (LDS form, one ray per lane)
     float       phase1_range{48.F}; // T1 of the cooperative kernel [px]
     std::string last_error;
@@ -175,6 +182,13 @@ OkStepParams baseParams(okenv *h)
     p.chead         = h->d_chead;
     p.P             = h->P;
     p.mlp_w         = h->d_mlp_w;
+    p.q_table       = h->d_q_table;
+    p.q_state       = h->d_q_state;
+    p.q_action      = h->d_q_action;
+    p.q_prev_idx    = h->d_q_prev;
+    for (int i = 0; i < 5; ++i)
+        p.q_ray[i] = h->q_ray[i];
+    p.q_epsilon = h->q_epsilon;
     return p;
 }
 
@@ -213,22 +227,41 @@ int launchStep(okenv *h, const OkStepParams &p)
     if (rc != OKENV_OK)
         return rc;
     const dim3 grid(h->grid_blocks), block(h->block_threads);
+    const int  policy = p.action_source == kActionsMlpPolicy ? kPolicyMlp : kPolicyNone;
+#define OK_LAUNCH_GENERIC(MODE, LDS)                                                                                   \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (policy == kPolicyMlp)                                                                                      \
+            hipLaunchKernelGGL((okStepKernel<MODE, kPolicyMlp>), grid, block, LDS, h->stream, p);                      \
+        else                                                                                                           \
+            hipLaunchKernelGGL((okStepKernel<MODE, kPolicyNone>), grid, block, LDS, h->stream, p);                     \
+    } while (0)
     switch (h->grid_mode)
     {
     case kGridLds:
         if (h->coop)
-            hipLaunchKernelGGL(okStepCoopKernel, grid, block, h->image_bytes + coopBytes(h->block_threads), h->stream, p,
-                               static_cast<uint32_t>(h->image_bytes), h->phase1_range);
+        {
+            const size_t   lds = h->image_bytes + coopBytes(h->block_threads);
+            const uint32_t off = static_cast<uint32_t>(h->image_bytes);
+            if (p.action_source == kActionsQLearning)
+                hipLaunchKernelGGL(okStepCoopKernel<kPolicyQ>, grid, block, lds + 8U * static_cast<size_t>(h->P) + 16U, h->stream, p, off,
+                                   h->phase1_range);
+            else if (policy == kPolicyMlp)
+                hipLaunchKernelGGL(okStepCoopKernel<kPolicyMlp>, grid, block, lds, h->stream, p, off, h->phase1_range);
+            else
+                hipLaunchKernelGGL(okStepCoopKernel<kPolicyNone>, grid, block, lds, h->stream, p, off, h->phase1_range);
+        }
         else
-            hipLaunchKernelGGL(okStepKernel<kGridLds>, grid, block, h->image_bytes, h->stream, p);
+            OK_LAUNCH_GENERIC(kGridLds, h->image_bytes);
         break;
     case kGridGlobal:
-        hipLaunchKernelGGL(okStepKernel<kGridGlobal>, grid, block, 0, h->stream, p);
+        OK_LAUNCH_GENERIC(kGridGlobal, 0);
         break;
     default:
-        hipLaunchKernelGGL(okStepKernel<kGridBrute>, grid, block, 0, h->stream, p);
+        OK_LAUNCH_GENERIC(kGridBrute, 0);
         break;
     }
+#undef OK_LAUNCH_GENERIC
     OK_HIP(h, hipGetLastError());
     return endTiming(h, ev);
 }
@@ -318,10 +351,17 @@ extern "C"
             h->d_image = dimg;
             OK_HIP(nullptr, hipMemcpyAsync(dimg, img.data(), h->image_bytes, hipMemcpyHostToDevice, h->stream));
             OK_HIP(nullptr, hipStreamSynchronize(h->stream));
-            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepKernel<kGridLds>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->image_bytes)));
-            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                static_cast<int>(h->image_bytes + coopBytes(1024))));
+            const int lds_plain = static_cast<int>(h->image_bytes), lds_coop = static_cast<int>(h->image_bytes + coopBytes(1024));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepKernel<kGridLds, kPolicyNone>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_plain));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepKernel<kGridLds, kPolicyMlp>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_plain));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyMlp>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyQ>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okDebugCastKernel<kGridLds>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->image_bytes)));
         }
@@ -353,6 +393,7 @@ extern "C"
             (rc = devAlloc(h, &s.dist, NR)) || (rc = devAlloc(h, &h->d_ray_deg, static_cast<size_t>(num_rays))))
             return fail(nullptr, rc, h->last_error);
         OK_HIP(nullptr, hipMemcpyAsync(h->d_ray_deg, ray_angles_deg, 4U * num_rays, hipMemcpyHostToDevice, h->stream));
+        h->host_ray_deg.assign(ray_angles_deg, ray_angles_deg + num_rays);
 
         // ---- launch geometry -------------------------------------------------------------------------
         // Spread small populations over the CUs: aim for >= 256 workgroups before growing them to 1024 lanes.
@@ -447,6 +488,10 @@ extern "C"
             (rc = devAlloc(h, &h->d_chead, static_cast<size_t>(num_points))))
             return rc;
         h->P = num_points;
+        h->host_cx.resize(num_points), h->host_cy.resize(num_points), h->host_chead.resize(num_points);
+        OK_HIP(h, hipMemcpy(h->host_cx.data(), x, 4U * num_points, hipMemcpyDefault));
+        OK_HIP(h, hipMemcpy(h->host_cy.data(), y, 4U * num_points, hipMemcpyDefault));
+        OK_HIP(h, hipMemcpy(h->host_chead.data(), heading_deg, 4U * num_points, hipMemcpyDefault));
         OK_HIP(h, hipMemcpyAsync(h->d_cx, x, 4U * num_points, hipMemcpyDefault, h->stream));
         OK_HIP(h, hipMemcpyAsync(h->d_cy, y, 4U * num_points, hipMemcpyDefault, h->stream));
         OK_HIP(h, hipMemcpyAsync(h->d_chead, heading_deg, 4U * num_points, hipMemcpyDefault, h->stream));
@@ -837,6 +882,127 @@ extern "C"
             OK_HIP(h, hipMemcpyAsync(parents_out, h->d_parents, sizeof(int32_t) * K, hipMemcpyDeviceToHost, h->stream));
             OK_HIP(h, hipStreamSynchronize(h->stream));
         }
+        return OKENV_OK;
+    }
+
+    // ---- RLRacers/Q_Learning ------------------------------------------------------------------------------------
+
+    int okenv_q_create(okenv_t h)
+    {
+        if (!h)
+            return OKENV_ERR_INVALID;
+        if (!h->coop || h->R < 5)
+            return fail(h, OKENV_ERR_INVALID, "okenv_q_create: needs the LDS form with 5 <= rays <= 64");
+        OK_HIP(h, hipSetDevice(h->device));
+        const size_t n = static_cast<size_t>(h->N) * OK_Q_STATES * OK_Q_ACTIONS;
+        int          rc;
+        if (!h->d_q_table)
+        {
+            if ((rc = devAlloc(h, &h->d_q_table, n)) || (rc = devAlloc(h, &h->d_q_state, static_cast<size_t>(h->N))) ||
+                (rc = devAlloc(h, &h->d_q_action, static_cast<size_t>(h->N))) || (rc = devAlloc(h, &h->d_q_prev, static_cast<size_t>(h->N))) ||
+                (rc = devAlloc(h, &h->d_q_reset_nearest, 4U)))
+                return rc;
+        }
+        hipLaunchKernelGGL(okQInitTableKernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, h->stream, h->d_q_table,
+                           static_cast<long>(n));
+        OK_HIP(h, hipGetLastError());
+        // the five rays of the state: nearest to -70, -30, 0, 30, 70 degrees, ties to the lower index
+        const float target[5] = {-70.F, -30.F, 0.F, 30.F, 70.F};
+        for (int t = 0; t < 5; ++t)
+        {
+            int   arg  = 0;
+            float best = std::fabs(h->host_ray_deg[0] - target[t]);
+            for (int r = 1; r < h->R; ++r)
+            {
+                const float d = std::fabs(h->host_ray_deg[r] - target[t]);
+                if (d < best)
+                {
+                    best = d;
+                    arg  = r;
+                }
+            }
+            h->q_ray[t] = arg;
+        }
+        return OKENV_OK;
+    }
+
+    int okenv_q_begin_episode(okenv_t h, int32_t reset_idx)
+    {
+        if (!h || !h->d_q_table)
+            return fail(h, OKENV_ERR_STATE, "okenv_q_begin_episode: call okenv_q_create first");
+        if (h->P <= 0 || reset_idx < 0 || reset_idx >= h->P)
+            return fail(h, OKENV_ERR_INVALID, "okenv_q_begin_episode: needs a centre line and a valid reset index");
+        const float x = h->host_cx[reset_idx], y = h->host_cy[reset_idx];
+        int         rc = okenv_reset_all(h, x, y, h->host_chead[reset_idx]);
+        if (rc != OKENV_OK)
+            return rc;
+        // prev_track_idx_ = findNearestTrackIndexBruteForce(reset point) (q_racer_sim.cpp:134-139); one query on the device
+        float *dq = nullptr;
+        OK_HIP(h, hipMallocAsync(reinterpret_cast<void **>(&dq), 8U, h->stream));
+        const float q[2] = {x, y};
+        OK_HIP(h, hipMemcpyAsync(dq, q, 8U, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(okNearestIdxKernel, dim3(1), dim3(256), 0, h->stream, h->d_cx, h->d_cy, h->P, dq, dq + 1, 1, h->d_q_reset_nearest);
+        OK_HIP(h, hipGetLastError());
+        OK_HIP(h, hipFreeAsync(dq, h->stream));
+        if ((rc = okenv_step(h, 1)) != OKENV_OK) // initial observation with the zero action Agent::reset leaves behind
+            return rc;
+        hipLaunchKernelGGL(okQBeginEpisodeKernel, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->st.dist, h->R, h->q_ray[0], h->q_ray[1],
+                           h->q_ray[2], h->q_ray[3], h->q_ray[4], h->d_q_state, h->d_q_prev, h->d_q_reset_nearest, h->N);
+        OK_HIP(h, hipGetLastError());
+        return OKENV_OK;
+    }
+
+    int okenv_rollout_q(okenv_t h, int32_t n_steps, float epsilon, uint32_t seed, uint32_t agent_base, uint32_t step_base)
+    {
+        if (!h || n_steps < 0)
+            return fail(h, OKENV_ERR_INVALID, "okenv_rollout_q: bad argument");
+        if (!h->d_q_table)
+            return fail(h, OKENV_ERR_STATE, "okenv_rollout_q: call okenv_q_create first");
+        if (n_steps == 0)
+            return OKENV_OK;
+        if (h->image_bytes + coopBytes(h->block_threads) + 8U * static_cast<size_t>(h->P) + 16U > kLdsBudget)
+            return fail(h, OKENV_ERR_STATE, "okenv_rollout_q: track image + centre line do not fit the CU's LDS");
+        h->q_epsilon    = epsilon;
+        OkStepParams p  = baseParams(h);
+        p.n_steps       = n_steps;
+        p.action_source = kActionsQLearning;
+        p.seed          = seed;
+        p.agent_base    = agent_base;
+        p.step_base     = step_base;
+        return launchStep(h, p);
+    }
+
+    int okenv_q_get_table(okenv_t h, float *out)
+    {
+        if (!h || !out || !h->d_q_table)
+            return fail(h, OKENV_ERR_STATE, "okenv_q_get_table: no table");
+        int rc = copyAny(h, out, h->d_q_table, sizeof(float) * static_cast<size_t>(h->N) * OK_Q_STATES * OK_Q_ACTIONS);
+        if (rc != OKENV_OK)
+            return rc;
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        return OKENV_OK;
+    }
+
+    int okenv_q_set_table(okenv_t h, const float *in)
+    {
+        if (!h || !in || !h->d_q_table)
+            return fail(h, OKENV_ERR_STATE, "okenv_q_set_table: no table");
+        int rc = copyAny(h, h->d_q_table, in, sizeof(float) * static_cast<size_t>(h->N) * OK_Q_STATES * OK_Q_ACTIONS);
+        if (rc != OKENV_OK)
+            return rc;
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        return OKENV_OK;
+    }
+
+    int okenv_q_get_state(okenv_t h, int32_t *state, int32_t *action, int32_t *prev_idx)
+    {
+        if (!h || !h->d_q_table)
+            return fail(h, OKENV_ERR_STATE, "okenv_q_get_state: no table");
+        int rc;
+        if ((state && (rc = copyAny(h, state, h->d_q_state, 4U * h->N))) || (action && (rc = copyAny(h, action, h->d_q_action, 4U * h->N))) ||
+            (prev_idx && (rc = copyAny(h, prev_idx, h->d_q_prev, 4U * h->N))))
+            return rc;
+        OK_HIP(h, hipStreamSynchronize(h->stream));
         return OKENV_OK;
     }
 

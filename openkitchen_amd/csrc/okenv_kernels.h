@@ -50,6 +50,7 @@ enum OkActionSource : int
     kActionsStored      = 0, // use thr/steer arrays as they are (set by the host between launches)
     kActionsPhiloxReset = 1, // bench recipe: per step reset crashed agents, draw U[0,100) x U[-5,5)
     kActionsMlpPolicy   = 2, // EvolutionaryRacer: per step GeneticAgent::updateAction from the previous observation
+    kActionsQLearning   = 3, // RLRacers/Q_Learning: epsilon-greedy action before the step, reward + table update after it
 };
 
 struct OkStepParams
@@ -79,6 +80,20 @@ struct OkStepParams
     int          P;
     // EvolutionaryRacer policy weights, OK_MLP_WEIGHTS(R) floats per agent (layout in okenv_math.h)
     const float *mlp_w;
+    // RLRacers/Q_Learning: per-agent table [N][243][3], current state / action / previous track index, the five
+    // rays that feed the state, epsilon of this rollout
+    float   *q_table;
+    int32_t *q_state, *q_action, *q_prev_idx;
+    int      q_ray[5];
+    float    q_epsilon;
+};
+
+// Compile-time policy selector of the step kernels, so that the headline path carries no policy registers.
+enum OkPolicyKind : int
+{
+    kPolicyNone = 0, // actions stored by the host, or the bench driver's Philox actions
+    kPolicyMlp  = 1, // EvolutionaryRacer
+    kPolicyQ    = 2, // RLRacers/Q_Learning
 };
 
 enum OkGridMode : int
@@ -351,8 +366,6 @@ okMlpAction(const OkStepParams &p, const int a, const int rlane, const int G, Ok
 __device__ __forceinline__ void
 okPolicyAction(const OkStepParams &p, const int a, const int rlane, const int G, OkAgentRegs &ag, const float dist_self, const bool ray_ok)
 {
-    if (p.action_source != kActionsMlpPolicy)
-        return;
     if (G >= 32)
         okMlpAction<1>(p, a, rlane, G, ag, dist_self, ray_ok);
     else if (G == 16)
@@ -379,7 +392,7 @@ __device__ __forceinline__ OkPolyView okSetupView(const OkStepParams &p, unsigne
 
 // Generic step kernel: every lane casts its own ray(s) from start to end.  Used for the global-memory and
 // brute-force forms, and for fans wider than 64 rays.
-template <int kMode>
+template <int kMode, int kPolicy>
 __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
@@ -395,11 +408,12 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
     OkAgentRegs ag      = okLoadAgent(p.st, a);
     // the policy reads the previous observation of this lane's ray (one ray per lane whenever a policy is attached)
     const bool pol_ray = agent_ok && (rlane < p.R);
-    float      last_dist = (p.action_source == kActionsMlpPolicy && pol_ray) ? p.st.dist[static_cast<long>(a) * p.R + rlane] : 0.F;
+    float      last_dist = (kPolicy != kPolicyNone && pol_ray) ? p.st.dist[static_cast<long>(a) * p.R + rlane] : 0.F;
 
     for (int s = 0; s < p.n_steps; ++s)
     {
-        okPolicyAction(p, a, rlane, G, ag, last_dist, pol_ray);
+        if (kPolicy == kPolicyMlp)
+            okPolicyAction(p, a, rlane, G, ag, last_dist, pol_ray);
         okAgentPreStep(p, ag, a, s);
         // ---- collision pass (CollisionChecker.cu:113-174) ------------------------------------------------
         float sr, cr;
@@ -466,6 +480,7 @@ struct OkCoopLds
     uint32_t *counter; // [2], alternating by step parity
 };
 
+template <int kPolicy>
 __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, const uint32_t off_coop, const float phase1_range)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
@@ -475,6 +490,17 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
     co.counter = reinterpret_cast<uint32_t *>(co.result + blockDim.x);
     if (threadIdx.x < 2)
         co.counter[threadIdx.x] = 0U;
+    // Q-learning scans the centre line every step (reward = progress along it): keep it in LDS, after the counters
+    float *lds_cx = reinterpret_cast<float *>(co.counter + 4);
+    float *lds_cy = lds_cx + p.P;
+    if (kPolicy == kPolicyQ)
+    {
+        for (int i = threadIdx.x; i < p.P; i += blockDim.x)
+        {
+            lds_cx[i] = p.cx[i];
+            lds_cy[i] = p.cy[i];
+        }
+    }
     const OkPolyView view = okSetupView<kGridLds>(p, ok_lds); // ends with a barrier
 
     const int  G        = p.G;
@@ -488,7 +514,16 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
     const long k        = static_cast<long>(a) * p.R + (ray_ok ? r : 0);
     const float ray_deg = p.ray_deg[ray_ok ? r : 0];
     OkAgentRegs ag      = okLoadAgent(p.st, a);
-    float       last_dist = (p.action_source == kActionsMlpPolicy && ray_ok) ? p.st.dist[k] : 0.F;
+    float       last_dist = (kPolicy != kPolicyNone && ray_ok) ? p.st.dist[k] : 0.F;
+    int         q_state = 0, q_action = 0, q_prev = 0;
+    float      *q_row0 = nullptr; // this agent's table
+    if (kPolicy == kPolicyQ)
+    {
+        q_state  = p.q_state[a];
+        q_action = p.q_action[a];
+        q_prev   = p.q_prev_idx[a];
+        q_row0   = p.q_table + static_cast<size_t>(a) * (OK_Q_STATES * OK_Q_ACTIONS);
+    }
 
 #if defined(OKENV_STAMPS)
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
@@ -506,7 +541,18 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
     for (int s = 0; s < p.n_steps; ++s)
     {
         const int par = s & 1;
-        okPolicyAction(p, a, r, G, ag, last_dist, ray_ok);
+        if (kPolicy == kPolicyMlp)
+            okPolicyAction(p, a, r, G, ag, last_dist, ray_ok);
+        if (kPolicy == kPolicyQ)
+        { // QLearnAgent::updateAction (QAgent.hpp:98-119); table reads bypass L1 (lane 0 of the group rewrites rows)
+            const float *row = q_row0 + q_state * OK_Q_ACTIONS;
+            const float  q0  = __hip_atomic_load(row + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float  q1  = __hip_atomic_load(row + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float  q2  = __hip_atomic_load(row + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q_action         = ok_q_choose_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s),
+                                                  p.q_epsilon, q0, q1, q2);
+            ok_q_action_values(q_action, &ag.thr, &ag.steer);
+        }
         okAgentPreStep(p, ag, a, s);
         float sr, cr;
         ok_sincosf(OK_DEG2RAD * ag.rot, &sr, &cr);
@@ -590,7 +636,63 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
         min_d2 = okGroupMin(min_d2, G);
         if (min_d2 < OK_CRASH_DIST2)
             ag.crashed = true;
+        if (kPolicy == kPolicyQ)
+        { // q_racer_sim.cpp:171-182: next state, reward from the progress along the centre line, table update
+            int next_state = 0, mult = 1;
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+            {
+                next_state += ok_q_bin(__shfl(last_dist, p.q_ray[i], G)) * mult;
+                mult *= 3;
+            }
+            // RaceTrack::findNearestTrackIndexBruteForce, the agent's G lanes striding over the centre line; strict '<'
+            // per lane and (distance, index) order across lanes keep the sequential scan's "lowest index wins"
+            float best = 3.402823466e+38F;
+            int   bi   = 0x7FFFFFFF;
+            for (int i = r; i < p.P; i += G)
+            {
+                const float dx = ag.pos_x - lds_cx[i], dy = ag.pos_y - lds_cy[i];
+                const float d2 = dx * dx + dy * dy;
+                if (d2 < best)
+                {
+                    best = d2;
+                    bi   = i;
+                }
+            }
+            for (int off = 1; off < G; off <<= 1)
+            {
+                const float ob = __shfl_xor(best, off, 64);
+                const int   oi = __shfl_xor(bi, off, 64);
+                if (ob < best || (ob == best && oi < bi))
+                {
+                    best = ob;
+                    bi   = oi;
+                }
+            }
+            const int   nearest = (bi == 0x7FFFFFFF) ? 0 : bi;
+            const float reward  = ok_q_reward(ag.crashed ? 1 : 0, nearest, &q_prev, p.P);
+            const float *nrow   = q_row0 + next_state * OK_Q_ACTIONS;
+            const float  n0     = __hip_atomic_load(nrow + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float  n1     = __hip_atomic_load(nrow + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float  n2     = __hip_atomic_load(nrow + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float        mq     = n0;
+            mq                  = (n1 > mq) ? n1 : mq;
+            mq                  = (n2 > mq) ? n2 : mq;
+            float *cell         = q_row0 + q_state * OK_Q_ACTIONS + q_action;
+            const float old_q   = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float new_q   = ok_q_learn(old_q, mq, reward);
+            if (agent_ok && r == 0)
+                __hip_atomic_store(cell, new_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!ag.crashed)
+                q_state = next_state;
+        }
         OK_STAMP(5);
+    }
+    if (kPolicy == kPolicyQ && agent_ok && r == 0)
+    {
+        p.q_state[a]    = q_state;
+        p.q_action[a]   = q_action;
+        p.q_prev_idx[a] = q_prev;
     }
 #if defined(OKENV_STAMPS)
     if ((threadIdx.x & 63) == 0)
@@ -822,6 +924,28 @@ __global__ void okGaMateKernel(const float *w_old, float *w_new, const int32_t *
             out = (ok_u01(r.v[2]) < 0.75F) ? wd : wsub;
     }
     w_new[t] = real ? out : 0.F;
+}
+
+// ---- RLRacers/Q_Learning service kernels ----------------------------------------------------------------------
+
+__global__ void okQInitTableKernel(float *q, long n)
+{
+    const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n)
+        q[i] = OK_Q_INVALID; // QAgent.hpp:64-68
+}
+
+// start of an episode (q_racer_sim.cpp:132-154, after the initial env.step()): current state from the fresh
+// observation, previous track index = the reset point's nearest index
+__global__ void okQBeginEpisodeKernel(const float *dist, int R, int r0, int r1, int r2, int r3, int r4, int32_t *q_state, int32_t *q_prev,
+                                      const int32_t *reset_nearest, int N)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= N)
+        return;
+    const float *d = dist + static_cast<long>(a) * R;
+    q_state[a]     = ok_q_bin(d[r0]) + 3 * ok_q_bin(d[r1]) + 9 * ok_q_bin(d[r2]) + 27 * ok_q_bin(d[r3]) + 81 * ok_q_bin(d[r4]);
+    q_prev[a]      = reset_nearest[0];
 }
 
 __global__ void okDebugSincosKernel(const float *x, float *s, float *c, int n)

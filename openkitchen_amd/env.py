@@ -216,6 +216,30 @@ class BatchedEnvironment:
         capi.check(self._L.okenv_ga_select_mate(self._h, int(seed), int(generation), int(agent_base), capi.ptr(parents)), self._h)
         return parents
 
+    # ---- RLRacers/Q_Learning on the device (include/okenv.h) -------------------------------------------------
+    def q_create(self):
+        capi.check(self._L.okenv_q_create(self._h), self._h)
+
+    def q_begin_episode(self, reset_idx):
+        capi.check(self._L.okenv_q_begin_episode(self._h, int(reset_idx)), self._h)
+
+    def rollout_q(self, n_steps, epsilon, seed, agent_base=0, step_base=0):
+        capi.check(self._L.okenv_rollout_q(self._h, int(n_steps), float(epsilon), int(seed), int(agent_base), int(step_base)), self._h)
+
+    def q_table(self):
+        out = np.zeros((self.N, 243, 3), dtype=np.float32)
+        capi.check(self._L.okenv_q_get_table(self._h, capi.ptr(out)), self._h)
+        return out
+
+    def set_q_table(self, table):
+        t = np.ascontiguousarray(table, dtype=np.float32)
+        capi.check(self._L.okenv_q_set_table(self._h, capi.ptr(t)), self._h)
+
+    def q_state(self):
+        s, a, p = (np.zeros(self.N, dtype=np.int32) for _ in range(3))
+        capi.check(self._L.okenv_q_get_state(self._h, capi.ptr(s), capi.ptr(a), capi.ptr(p)), self._h)
+        return s, a, p
+
     # ---- measurement / self-checks ------------------------------------------------------------------
     def set_timing(self, enabled):
         capi.check(self._L.okenv_set_timing(self._h, 1 if enabled else 0), self._h)

@@ -287,6 +287,10 @@ typedef struct oracle_env {
     /* EvolutionaryRacer: per-agent MLP weights (padded layout of okenv_math.h), scores */
     int mlp_hidden;
     float *mlp_w, *score;
+    /* RLRacers/Q_Learning: table [N][243][3], state/action/prev index per agent, the five state rays */
+    float *q_table;
+    int32_t *q_state, *q_action, *q_prev;
+    int q_ray[5];
 } oracle_env;
 
 #define ALLOC(T, n) ((T *)calloc((size_t)(n), sizeof(T)))
@@ -319,6 +323,7 @@ ORACLE_API void oracle_env_destroy(oracle_env *e)
     free(e->hit_x); free(e->hit_y); free(e->rel_x); free(e->rel_y); free(e->dist);
     free(e->cx); free(e->cy); free(e->chead);
     free(e->mlp_w); free(e->score);
+    free(e->q_table); free(e->q_state); free(e->q_action); free(e->q_prev);
     free(e);
 }
 
@@ -744,4 +749,124 @@ ORACLE_API void oracle_ga_select_mate(oracle_env *e, uint32_t seed, uint32_t gen
     }
     free(e->mlp_w);
     e->mlp_w = nw;
+}
+
+/* ============================================================================================ */
+/* RLRacers/Q_Learning                                            */
+/* ============================================================================================ */
+
+#define Q_STATES 243
+#define Q_ACTIONS 3
+static const float kQInvalid = -FLT_MAX; /* numeric_limits<float>::lowest(), QAgent.hpp:36 */
+
+ORACLE_API void oracle_q_create(oracle_env *e)
+{
+    free(e->q_table); free(e->q_state); free(e->q_action); free(e->q_prev);
+    const size_t n = (size_t)e->N * Q_STATES * Q_ACTIONS;
+    e->q_table = ALLOC(float, n);
+    for (size_t i = 0; i < n; ++i) e->q_table[i] = kQInvalid; /* QAgent.hpp:64-68 */
+    e->q_state = ALLOC(int32_t, e->N); e->q_action = ALLOC(int32_t, e->N); e->q_prev = ALLOC(int32_t, e->N);
+    const float target[5] = {-70.0f, -30.0f, 0.0f, 30.0f, 70.0f}; /* the reference's five rays, QAgent.hpp:56-62 */
+    for (int t = 0; t < 5; ++t) {
+        int arg = 0; float best = fabsf(e->ray_deg[0] - target[t]);
+        for (int r = 1; r < e->R; ++r) {
+            const float d = fabsf(e->ray_deg[r] - target[t]);
+            if (d < best) { best = d; arg = r; }
+        }
+        e->q_ray[t] = arg;
+    }
+}
+
+/* QLearnAgent::discretizeState (QAgent.hpp:72-94) over the five state rays */
+static int q_discretize(const oracle_env *e, int a)
+{
+    int state = 0, mult = 1;
+    for (int i = 0; i < 5; ++i) {
+        const float d = e->dist[(size_t)a * e->R + e->q_ray[i]];
+        int bin;
+        if (d < 5.0f) bin = 0;
+        else if (d < 10.0f) bin = 1;
+        else bin = 2;
+        state += bin * mult;
+        mult *= 3;
+    }
+    return state;
+}
+
+static int nearest_index(const oracle_env *e, float x, float y)
+{
+    float best = FLT_MAX; int bi = 0;
+    for (int i = 0; i < e->P; ++i) {
+        const float dx = x - e->cx[i], dy = y - e->cy[i];
+        const float d = dx * dx + dy * dy;
+        if (d < best) { best = d; bi = i; }
+    }
+    return bi;
+}
+
+/* q_racer_sim.cpp:129-154 */
+ORACLE_API void oracle_q_begin_episode(oracle_env *e, int reset_idx)
+{
+    const float x = e->cx[reset_idx], y = e->cy[reset_idx];
+    const int near = nearest_index(e, x, y);
+    for (int a = 0; a < e->N; ++a) { agent_reset(e, a, x, y, e->chead[reset_idx]); e->q_prev[a] = near; }
+    step_range(e, 0, e->N);
+    for (int a = 0; a < e->N; ++a) e->q_state[a] = q_discretize(e, a);
+}
+
+/* q_racer_sim.cpp:158-182 with QAgent.hpp:98-119 (updateAction), :150-168 (reward), :121-138 (learn) */
+ORACLE_API void oracle_rollout_q(oracle_env *e, int n_steps, float epsilon, uint32_t seed, uint32_t agent_base, uint32_t step_base)
+{
+    for (int s = 0; s < n_steps; ++s) {
+        for (int a = 0; a < e->N; ++a) {
+            float *row = e->q_table + ((size_t)a * Q_STATES + e->q_state[a]) * Q_ACTIONS;
+            const ok_u32x4 r = ok_philox4x32(agent_base + (uint32_t)a, step_base + (uint32_t)s, 4u, 0u, seed, 0x6F6B656Eu);
+            int act;
+            if (ok_u01(r.v[0]) < epsilon) {
+                act = (int)(ok_u01(r.v[1]) * 3.0f);
+                if (act > 2) act = 2;
+            } else { /* std::max_element: first maximum */
+                act = 0;
+                if (row[1] > row[act]) act = 1;
+                if (row[2] > row[act]) act = 2;
+            }
+            e->q_action[a] = act;
+            /* kActionMap, QAgent.hpp:40-42 */
+            e->thr[a] = (act == 0) ? 60.0f : 30.0f;
+            e->steer[a] = (act == 0) ? 0.0f : (act == 1 ? 5.0f : -5.0f);
+        }
+        step_range(e, 0, e->N);
+        for (int a = 0; a < e->N; ++a) {
+            const int next_state = q_discretize(e, a);
+            float reward;
+            if (e->crashed[a]) {
+                reward = -200.0f;
+            } else {
+                const int near = nearest_index(e, e->pos_x[a], e->pos_y[a]);
+                long prog = (long)near - (long)e->q_prev[a];
+                e->q_prev[a] = near;
+                if (prog < 0) prog = -prog;
+                reward = (float)((prog > (long)(e->P / 2)) ? (long)e->P - prog : prog);
+            }
+            const float *nrow = e->q_table + ((size_t)a * Q_STATES + next_state) * Q_ACTIONS;
+            float maxq = nrow[0];
+            if (nrow[1] > maxq) maxq = nrow[1];
+            if (nrow[2] > maxq) maxq = nrow[2];
+            float *cell = e->q_table + ((size_t)a * Q_STATES + e->q_state[a]) * Q_ACTIONS + e->q_action[a];
+            const float target = reward + 0.8f * maxq;
+            const float old_q = *cell;
+            if (old_q == kQInvalid || maxq == kQInvalid) *cell = reward;
+            else *cell = old_q + 0.2f * (target - old_q);
+            if (!e->crashed[a]) e->q_state[a] = next_state;
+        }
+    }
+}
+
+ORACLE_API void oracle_q_get_table(const oracle_env *e, float *out)
+{
+    memcpy(out, e->q_table, sizeof(float) * (size_t)e->N * Q_STATES * Q_ACTIONS);
+}
+ORACLE_API void oracle_q_get_state(const oracle_env *e, int32_t *state, int32_t *action, int32_t *prev)
+{
+    memcpy(state, e->q_state, 4 * (size_t)e->N); memcpy(action, e->q_action, 4 * (size_t)e->N); memcpy(prev, e->q_prev, 4 * (size_t)e->N);
 }

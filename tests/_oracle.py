@@ -81,6 +81,11 @@ def lib():
         L.oracle_env_reset_all.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
         L.oracle_ga_scores.argtypes = [C.c_void_p, f32p]
         L.oracle_ga_select_mate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, i32p]
+        L.oracle_q_create.argtypes = [C.c_void_p]
+        L.oracle_q_begin_episode.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_rollout_q.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.oracle_q_get_table.argtypes = [C.c_void_p, f32p]
+        L.oracle_q_get_state.argtypes = [C.c_void_p, i32p, i32p, i32p]
         _lib = L
     return _lib
 
@@ -243,3 +248,27 @@ class OracleGA:
         parents = np.zeros(5, dtype=np.int32)
         lib().oracle_ga_select_mate(self.env.h, seed, generation, agent_base, parents)
         return parents
+
+
+class OracleQ:
+    """RLRacers/Q_Learning helpers on top of an OracleEnv."""
+
+    def __init__(self, env):
+        self.env = env
+        lib().oracle_q_create(env.h)
+
+    def begin_episode(self, reset_idx):
+        lib().oracle_q_begin_episode(self.env.h, int(reset_idx))
+
+    def rollout(self, n, epsilon, seed, agent_base=0, step_base=0):
+        lib().oracle_rollout_q(self.env.h, n, float(epsilon), seed, agent_base, step_base)
+
+    def table(self):
+        t = np.zeros(self.env.N * 243 * 3, dtype=np.float32)
+        lib().oracle_q_get_table(self.env.h, t)
+        return t.reshape(self.env.N, 243, 3)
+
+    def state(self):
+        s, a, p = (np.zeros(self.env.N, dtype=np.int32) for _ in range(3))
+        lib().oracle_q_get_state(self.env.h, s, a, p)
+        return s, a, p
