@@ -128,6 +128,50 @@ def bench_evolution(args, ok, torch, dist, rank, world, local_rank, log):
         dist.destroy_process_group()
 
 
+def bench_qlearning(args, ok, torch, dist, rank, world, local_rank, log):
+    """BASELINE config 5: 16384 parallel Q-learning agents x 16 rays, discretised observation, device-side Q-table update."""
+    from openkitchen_amd import sharding
+    from openkitchen_amd.qlearning import QLearningRacers
+
+    N, R = 16384, 16
+    track = ok.Track(args.track)
+    env = ok.BatchedEnvironment.from_track(track, N, R, device=local_rank)
+    ql = QLearningRacers(env, track, seed=args.seed + rank, agent_base=rank * N, steps_per_launch=args.steps_per_launch)
+    ql.run_episode()  # warm-up episode
+    env.sync()
+    torch.cuda.synchronize()
+    sharding.barrier(device_ids=[local_rank])
+    t0 = time.perf_counter()
+    steps, recs = 0, []
+    while steps < args.steps:
+        r = ql.run_episode()
+        recs.append(r)
+        steps += r["steps"]
+    env.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    sharding.barrier(device_ids=[local_rank])
+    elapsed_max = sharding.max_over_ranks(elapsed, device="cuda")
+    steps_t = torch.tensor([float(steps)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(steps_t)
+    if rank == 0:
+        table = env.q_table()
+        print(json.dumps({
+            "metric": "agent-steps/sec", "value": N * float(steps_t.item()) / elapsed_max, "unit": "agent-steps/s", "n_gpus": world,
+            "steps": steps, "warmup": 0, "ms_per_step": elapsed_max / max(steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C5: tabular Q-learning, %d agents x %d rays per GPU, %s.csv, epsilon-greedy + reward + Q update fused into "
+                                   "the step kernel, 243x3 table per agent (%.1f MB)" % (N, R, args.track, N * 243 * 3 * 4 / 1e6),
+                       "episodes": len(recs), "parallelism": "dp%d" % world},
+            "episodes": recs, "learned_entries_fraction": float((table > -1e30).mean()),
+        }), flush=True)
+    env.close()
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,7 +185,7 @@ def main():
                     help="Environment steps advanced by one kernel launch (the action source is on the device)")
     ap.add_argument("--grid-cell", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"],
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2: headline (random actions); c3/c4: EvolutionaryRacer generations (population 8192 x 32 rays per GPU, "
                          "Monza / Spa, fused MLP policy, score, select, mate; c4 adds the per-generation RCCL fitness all-gather)")
     ap.add_argument("--generations", type=int, default=5)
@@ -174,6 +218,8 @@ def main():
     ok.build()
     if args.config in ("c3", "c4"):
         return bench_evolution(args, ok, torch, dist, rank, world, local_rank, log)
+    if args.config == "c5":
+        return bench_qlearning(args, ok, torch, dist, rank, world, local_rank, log)
     track = ok.Track(args.track)
     N, R = args.agents, args.rays
     env = ok.BatchedEnvironment.from_track(track, N, R, device=local_rank, grid_cell=args.grid_cell)
