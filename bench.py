@@ -93,7 +93,7 @@ def bench_evolution(args, ok, torch, dist, rank, world, local_rank, log):
     track = ok.Track(track_name)
     env = ok.BatchedEnvironment.from_track(track, N, R, device=local_rank)
     ga = EvolutionaryRacer(env, track, hidden=30, seed=args.seed + rank, agent_base=rank * N, max_steps=4000,
-                           steps_per_launch=args.steps_per_launch, device="cuda")
+                           steps_per_launch=args.steps_per_launch, device=args.tensor_dev)
     ga.run_generation()  # warm-up generation (untimed)
     env.sync()
     torch.cuda.synchronize()
@@ -104,9 +104,9 @@ def bench_evolution(args, ok, torch, dist, rank, world, local_rank, log):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     sharding.barrier(device_ids=[local_rank])
-    elapsed_max = sharding.max_over_ranks(elapsed, device="cuda")
+    elapsed_max = sharding.max_over_ranks(elapsed, device=args.tensor_dev)
     steps = sum(r["steps"] for r in recs)
-    steps_t = torch.tensor([float(steps)], dtype=torch.float64, device="cuda")
+    steps_t = torch.tensor([float(steps)], dtype=torch.float64, device=args.tensor_dev)
     if world > 1:
         dist.all_reduce(steps_t)
     if rank == 0:
@@ -124,7 +124,7 @@ def bench_evolution(args, ok, torch, dist, rank, world, local_rank, log):
         }), flush=True)
     env.close()
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        sharding.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
@@ -151,8 +151,8 @@ def bench_qlearning(args, ok, torch, dist, rank, world, local_rank, log):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     sharding.barrier(device_ids=[local_rank])
-    elapsed_max = sharding.max_over_ranks(elapsed, device="cuda")
-    steps_t = torch.tensor([float(steps)], dtype=torch.float64, device="cuda")
+    elapsed_max = sharding.max_over_ranks(elapsed, device=args.tensor_dev)
+    steps_t = torch.tensor([float(steps)], dtype=torch.float64, device=args.tensor_dev)
     if world > 1:
         dist.all_reduce(steps_t)
     if rank == 0:
@@ -168,7 +168,7 @@ def bench_qlearning(args, ok, torch, dist, rank, world, local_rank, log):
         }), flush=True)
     env.close()
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        sharding.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
@@ -189,6 +189,9 @@ def main():
                     help="c2: headline (random actions); c3/c4: EvolutionaryRacer generations (population 8192 x 32 rays per GPU, "
                          "Monza / Spa, fused MLP policy, score, select, mate; c4 adds the per-generation RCCL fitness all-gather)")
     ap.add_argument("--generations", type=int, default=5)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, default).  gloo + --single-device rehearses the multi-process path on a one-GPU box")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the secondary one-launch-per-step and host-boundary loops (used under rocprofv3 so that the "
                          "kernel trace holds only the timed region's launches)")
@@ -205,9 +208,16 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the Environment step has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    tensor_dev = "cuda" if args.dist_backend == "nccl" else "cpu"  # where the tiny timing tensors live
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
+    args.tensor_dev = tensor_dev
 
     def log(msg):
         if rank == 0:
@@ -256,7 +266,7 @@ def main():
     sharding.barrier(device_ids=[local_rank])
     kernel_ms, launches = env.get_timing()
     env.set_timing(False)
-    elapsed_max = sharding.max_over_ranks(elapsed, device="cuda")
+    elapsed_max = sharding.max_over_ranks(elapsed, device=args.tensor_dev)
 
     # ---- secondary figure: one launch per step (what a host-side policy between steps would see) ----
     one_steps = 0 if args.headline_only else min(args.steps, 500)
@@ -337,7 +347,7 @@ def main():
         print(json.dumps(result), flush=True)
     env.close()
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        sharding.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
