@@ -266,11 +266,18 @@ OKRC_HD float ok_side(const OkPoint p, const float ox, const float oy, const flo
     return __builtin_fmaf(ax, rdy, -(ay * rdx));
 }
 
-// true when the segment whose end points have sides s0, s1 cannot be hit (see the header comment):
-// equal signs and both magnitudes above the tolerance.
+// true when the segment whose end points have sides s0, s1 cannot be hit (see the header comment): equal signs and
+// both magnitudes above the tolerance.  median(s0, s1, 0) is the side of smaller magnitude when the signs agree and 0
+// when they differ, so one v_med3_f32 and one compare decide it on the GPU.
 OKRC_HD bool ok_same_side(const float s0, const float s1, const float tol)
 {
-    return (s0 * s1 > 0.0F) && (__builtin_fminf(__builtin_fabsf(s0), __builtin_fabsf(s1)) > tol);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fabsf(__builtin_amdgcn_fmed3f(s0, s1, 0.0F)) > tol;
+#else
+    const float lo = __builtin_fminf(s0, s1), hi = __builtin_fmaxf(s0, s1);
+    const float med = (lo > 0.0F) ? lo : ((hi < 0.0F) ? hi : 0.0F);
+    return __builtin_fabsf(med) > tol;
+#endif
 }
 
 #define OKPOLY_NONE 0xFFFFFFFFU
