@@ -195,17 +195,18 @@ inline OkGridHost okBuildGrid(const OkSeg *segs, const size_t num_segments, floa
 //   slots[]   8 B per point.  Each cell owns a contiguous, 16-byte aligned range of slots holding, run after run,
 //             the points of the chained segments registered in it (a run of n chained segments = n + 1 points),
 //             padded to an even count with a copy of its last point.
-//   hdr[cell] first_slot | (n_slots << 20)
-//   brk[]     one bit per slot: set when NO segment joins slot k-1 to slot k (first point of a run, padding).
-// Consecutive slots k, k+1 with brk(k+1) clear are one registered segment; because chained segments of the
+//   hdr[cell] 8 bytes: { first_slot | (n_slots << 20), brk } where bit j of brk is set when NO segment joins slot
+//             first_slot + j - 1 to slot first_slot + j (first point of a run, padding).  n_slots <= 32.
+// Consecutive slots k, k+1 with the break bit of k+1 clear are one registered segment; because chained segments of the
 // reference's boundary polylines share end points bit for bit, a run costs one point per segment.
 struct OkPolyImage
 {
     bool                 ok{false}; // encodable (index/count fields wide enough)
     uint32_t             num_slots{0};
     uint32_t             num_runs{0};
-    std::vector<uint8_t> bytes;     // slots | hdr | brk, each part 16-byte aligned
-    size_t               off_hdr{0}, off_brk{0};
+    std::vector<uint8_t> bytes;     // slots | hdr, each part 16-byte aligned
+    size_t               off_hdr{0};
+    uint32_t             max_slots_per_cell{0};
     float                side_tol{0.F};
     float                max_seg_len{0.F};
 };
@@ -230,15 +231,17 @@ inline OkPolyImage okBuildPolyImage(const OkSeg *segs, const size_t num_segments
                                                     static_cast<double>(segs[i].y2) - segs[i].y1));
     }
     img.max_seg_len = static_cast<float>(max_len);
-    const size_t          ncell = grid.numCells();
-    std::vector<OkPoint>  slots;
-    std::vector<uint8_t>  brk; // one byte per slot while building
-    std::vector<uint32_t> hdr(ncell, 0U);
-    const uint32_t        max_count = (1U << (32 - OKPOLY_IDX_BITS)) - 1U;
-    bool                  encodable = true;
+    const size_t           ncell = grid.numCells();
+    std::vector<OkPoint>   slots;
+    std::vector<uint8_t>   brk; // one byte per slot while building
+    std::vector<OkCellHdr> hdr(ncell, OkCellHdr{0U, 1U});
+    bool                   encodable = true;
+    std::vector<OkPoint>   cs; // the cell's slots before chunking
+    std::vector<uint8_t>   cb;
     for (size_t c = 0; c < ncell; ++c)
     {
-        const uint32_t first = static_cast<uint32_t>(slots.size()); // always even
+        cs.clear();
+        cb.clear();
         uint32_t       k     = grid.start[c];
         const uint32_t k_end = grid.start[c + 1];
         while (k < k_end)
@@ -247,25 +250,81 @@ inline OkPolyImage okBuildPolyImage(const OkSeg *segs, const size_t num_segments
             uint32_t       n    = 1;
             while (k + n < k_end && grid.refs[k + n] == seg0 + n && chained[seg0 + n])
                 ++n;
-            slots.push_back({segs[seg0].x1, segs[seg0].y1});
-            brk.push_back(1);
+            cs.push_back({segs[seg0].x1, segs[seg0].y1});
+            cb.push_back(1);
             for (uint32_t j = 0; j < n; ++j)
             {
-                slots.push_back({segs[seg0 + j].x2, segs[seg0 + j].y2});
-                brk.push_back(0);
+                cs.push_back({segs[seg0 + j].x2, segs[seg0 + j].y2});
+                cb.push_back(0);
             }
             ++img.num_runs;
             k += n;
         }
-        if ((slots.size() - first) & 1U)
+        if (cs.size() > img.max_slots_per_cell)
+            img.max_slots_per_cell = static_cast<uint32_t>(cs.size());
+        // emit chunks of at most 32 slots; a continuation chunk repeats its predecessor's last point, and its header
+        // lives in the slot stream right behind the predecessor's slots
+        size_t pos         = 0;
+        long   hdr_in_slot = -1; // slot index holding the header to fill (-1: the cell's own header)
+        bool   first       = true;
+        do
         {
-            slots.push_back(slots.back());
-            brk.push_back(1);
-        }
-        const uint32_t count = static_cast<uint32_t>(slots.size()) - first;
-        if (count > max_count || first > OKPOLY_IDX_MASK)
-            encodable = false;
-        hdr[c] = first | (count << OKPOLY_IDX_BITS);
+            const uint32_t first_slot = static_cast<uint32_t>(slots.size()); // always even
+            uint32_t       count      = 0U, bits = 0U;
+            if (!first)
+            { // overlap: the cut pair (cs[pos-1], cs[pos]) is examined in this chunk
+                slots.push_back(cs[pos - 1]);
+                brk.push_back(1);
+                bits |= 1U;
+                ++count;
+            }
+            while (pos < cs.size() && count < OKPOLY_MAX_SLOTS)
+            {
+                slots.push_back(cs[pos]);
+                brk.push_back(cb[pos]);
+                if (cb[pos])
+                    bits |= 1U << count;
+                ++pos;
+                ++count;
+            }
+            if (count & 1U)
+            {
+                if (count == OKPOLY_MAX_SLOTS)
+                { // cannot pad: give the last slot back to the next chunk
+                    slots.pop_back();
+                    brk.pop_back();
+                    --pos;
+                    --count;
+                    bits &= ~(1U << count);
+                }
+                if (count & 1U)
+                {
+                    slots.push_back(slots.back());
+                    brk.push_back(1);
+                    bits |= 1U << count;
+                    ++count;
+                }
+            }
+            if (first_slot > OKPOLY_IDX_MASK)
+                encodable = false;
+            const bool      more = pos < cs.size();
+            const OkCellHdr hv{first_slot | (count << OKPOLY_IDX_BITS) | ((more ? 1U : 0U) << (OKPOLY_IDX_BITS + 6)), bits | 1U};
+            if (hdr_in_slot < 0)
+                hdr[c] = hv;
+            else
+                std::memcpy(&slots[static_cast<size_t>(hdr_in_slot)], &hv, sizeof hv);
+            if (more)
+            { // reserve one slot for the next chunk's header plus one to keep chunks on even slots
+                hdr_in_slot = static_cast<long>(slots.size());
+                slots.push_back({0.F, 0.F});
+                slots.push_back({0.F, 0.F});
+                brk.push_back(1);
+                brk.push_back(1);
+            }
+            first = false;
+        } while (pos < cs.size() && encodable);
+        if (!encodable)
+            break;
     }
     slots.push_back({0.F, 0.F}); // the exact test of slot k reads k+1; keep the last read in bounds
     slots.push_back({0.F, 0.F});
@@ -275,19 +334,12 @@ inline OkPolyImage okBuildPolyImage(const OkSeg *segs, const size_t num_segments
     img.num_slots = static_cast<uint32_t>(slots.size());
     if (!encodable)
         return img;
-    std::vector<uint32_t> brk_bits((slots.size() + 31U) / 32U, 0U);
-    for (size_t i = 0; i < brk.size(); ++i)
-        if (brk[i])
-            brk_bits[i >> 5] |= 1U << (i & 31U);
     const size_t slot_b = OkGridHost::align16(slots.size() * sizeof(OkPoint));
-    const size_t hdr_b  = OkGridHost::align16(hdr.size() * 4U);
-    const size_t brk_b  = OkGridHost::align16(brk_bits.size() * 4U);
+    const size_t hdr_b  = OkGridHost::align16(hdr.size() * sizeof(OkCellHdr));
     img.off_hdr         = slot_b;
-    img.off_brk         = slot_b + hdr_b;
-    img.bytes.assign(slot_b + hdr_b + brk_b, 0);
+    img.bytes.assign(slot_b + hdr_b, 0);
     std::memcpy(img.bytes.data(), slots.data(), slots.size() * sizeof(OkPoint));
-    std::memcpy(img.bytes.data() + img.off_hdr, hdr.data(), hdr.size() * 4U);
-    std::memcpy(img.bytes.data() + img.off_brk, brk_bits.data(), brk_bits.size() * 4U);
+    std::memcpy(img.bytes.data() + img.off_hdr, hdr.data(), hdr.size() * sizeof(OkCellHdr));
     // side tolerance (ok_raycast.h): any point met by a walk lies within A = range + two cell diagonals + the
     // longest segment + margin of the ray origin; rounding differences between the skip rule's sides and the
     // reference's num_s / denom are below ~4 * 2^-23 * 4A; take 2^-17 * A (16x that).
@@ -307,7 +359,7 @@ inline OkGridHost okBuildGridAuto(const OkSeg *segs,
 {
     float      cell = requested > 0.F ? requested : 16.F;
     OkGridHost g;
-    for (int attempt = 0; attempt < 24; ++attempt)
+    for (int attempt = 0; attempt < 32; ++attempt)
     {
         g      = okBuildGrid(segs, num_segments, cell);
         *image = okBuildPolyImage(segs, num_segments, g);
@@ -318,7 +370,10 @@ inline OkGridHost okBuildGridAuto(const OkSeg *segs,
         }
         if (num_segments * 8U + 64U > lds_budget)
             break; // the points alone do not fit: no cell size will help
-        cell *= 1.25F;
+        if (image->ok)
+            cell *= 1.25F; // too big for LDS: fewer, larger cells
+        else
+            break; // more than 2^20 slots: the compact form cannot index them
     }
     *fits_lds = false;
     return okBuildGrid(segs, num_segments, requested > 0.F ? requested : 16.F);

@@ -83,17 +83,27 @@ struct OkGridView32
 };
 
 // Compact "poly" view, staged into LDS by the step kernel (layout built by ok_grid.h: a cell-major stream of
-// boundary points, a 4-byte header per cell and one "no segment ends here" bit per slot).
+// boundary points and an 8-byte header per cell).
+struct OkCellHdr
+{
+    uint32_t w0;  // first_slot (20 bits) | n_slots << 20 (6 bits, even, <= 32) | has_next << 26
+    uint32_t brk; // bit j set: NO segment joins slots first_slot + j - 1 and first_slot + j (run start, padding); bit 0 is set
+};
+// A cell with more than 32 slots continues in further chunks: when has_next is set, the next chunk's header occupies
+// the slot right after this chunk's slots (slot index first_slot + n_slots, 8 bytes, followed by one unused slot).  A
+// continuation chunk starts with a copy of its predecessor's last point, so the pair straddling the cut is examined.
+
 struct OkPolyView
 {
-    OkGridGeom      g;
-    const OkPoint  *slots;
-    const uint32_t *hdr; // first_slot | (n_slots << 20); n_slots is even, first_slot is even
-    const uint32_t *brk; // bit k set: slots k-1 and k are NOT joined by a segment
-    float           side_tol;
+    OkGridGeom       g;
+    const OkPoint   *slots;
+    const OkCellHdr *hdr;
+    float            side_tol;
 };
 #define OKPOLY_IDX_BITS 20
 #define OKPOLY_IDX_MASK 0xFFFFFU
+#define OKPOLY_MAX_SLOTS 32U
+#define OKPOLY_N_MASK 0x3FU
 
 struct OkPointPair // two consecutive slots, 16 bytes: one ds_read_b128
 {
@@ -280,19 +290,6 @@ OKRC_HD bool ok_same_side(const float s0, const float s1, const float tol)
 #endif
 }
 
-#define OKPOLY_NONE 0xFFFFFFFFU
-
-// Compact form.
-//  * Per cell the lane streams its slots two at a time (one 16-byte LDS read), evaluates the side of each point
-//    and applies the skip rule to every consecutive pair.  The next cell's header is fetched before the current
-//    cell is processed, so the dependent LDS round trips per cell are header -> points, nothing else.
-//  * Segments that survive the side rule are not tested on the spot: their first slot index is parked in a
-//    two-entry per-lane stack and the exact tests run once per cell, after the point loop.  On the GPU this
-//    keeps the long, division-heavy exact test out of the divergent inner loop: a wave pays for it once or
-//    twice per cell instead of once per straggling lane.  The order of exact tests does not matter (min is
-//    order independent) and every parked segment is tested before the cell's termination check, so the
-//    result is unchanged.
-// `tests` counts exact tests, `cells` cells, `points` point evaluations (statistics only).
 // exact test of the registered segment (slot k, slot k+1); returns the updated first-hit parameter
 OKRC_HD float okExactSlot(const OkPolyView &v,
                           const uint32_t    k,
@@ -308,45 +305,9 @@ OKRC_HD float okExactSlot(const OkPolyView &v,
     return ok_ray_segment(ox, oy, rdx, rdy, a.x, a.y, b.x, b.y, min_t, t) ? t : min_t;
 }
 
-// Per-lane state of the compact walk that the park/flush steps update.  Passed and returned BY VALUE: with
-// reference parameters hipcc turned `if (empty0) pend0 = k; else pend1 = k;` into a store through a selected
-// pointer, which kept the two-entry stack in scratch memory instead of registers.
-struct OkPending
+OKRC_HD uint32_t okCountTrailingZeros(const uint32_t x)
 {
-    uint32_t p0, p1; // first-slot indices of parked segments, OKPOLY_NONE when empty
-    float    min_t;
-};
-
-// Parks segment (k, k+1) unless slot k+1 starts a new run.
-template <bool kCount>
-OKRC_HD OkPending okPark(const OkPolyView &v,
-                         const uint32_t    k,
-                         OkPending         st,
-                         const float       ox,
-                         const float       oy,
-                         const float       rdx,
-                         const float       rdy,
-                         uint32_t         *tests)
-{
-    const uint32_t k1 = k + 1U;
-    if ((v.brk[k1 >> 5] >> (k1 & 31U)) & 1U)
-        return st;
-    const bool e0 = st.p0 == OKPOLY_NONE;
-    const bool e1 = st.p1 == OKPOLY_NONE;
-    if (!e0 && !e1)
-    { // three survivors in one cell: make room
-        if (kCount)
-            *tests += 1;
-        st.min_t = okExactSlot(v, st.p0, ox, oy, rdx, rdy, st.min_t);
-        st.p0    = st.p1;
-        st.p1    = k;
-    }
-    else
-    {
-        st.p1 = e0 ? st.p1 : k;
-        st.p0 = e0 ? k : st.p0;
-    }
-    return st;
+    return static_cast<uint32_t>(__builtin_ctz(x));
 }
 
 // What a walk over part of a ray reports.
@@ -379,9 +340,9 @@ OKRC_HD OkIntervalResult ok_cast_poly_interval(const OkPolyView &v,
     OkWalk            w;
     if (!w.init(g, ox, oy, rdx, rdy, t_a))
         return {OK_SENSOR_RANGE, OK_SENSOR_RANGE, true};
-    const float tol = v.side_tol;
-    OkPending   st{OKPOLY_NONE, OKPOLY_NONE, OK_SENSOR_RANGE};
-    uint32_t    h = v.hdr[w.iy * g.nx + w.ix];
+    const float tol   = v.side_tol;
+    float       min_t = OK_SENSOR_RANGE;
+    OkCellHdr   h     = v.hdr[w.iy * g.nx + w.ix];
     // The walk visits at most nx + ny cells; the explicit bound makes termination unconditional.
     for (int guard = g.nx + g.ny + 2; guard > 0; --guard)
     {
@@ -391,54 +352,56 @@ OKRC_HD OkIntervalResult ok_cast_poly_interval(const OkPolyView &v,
         int        ny_i = w.iy + (go_x ? 0 : w.step_y);
         nx_i            = nx_i < 0 ? 0 : (nx_i >= g.nx ? g.nx - 1 : nx_i);
         ny_i            = ny_i < 0 ? 0 : (ny_i >= g.ny ? g.ny - 1 : ny_i);
-        const uint32_t h_next = v.hdr[ny_i * g.nx + nx_i];
+        const OkCellHdr h_next = v.hdr[ny_i * g.nx + nx_i];
 
-        uint32_t       k     = h & OKPOLY_IDX_MASK;
-        const uint32_t k_end = k + (h >> OKPOLY_IDX_BITS);
         if (kCount)
-        {
             *cells += 1;
-            *points += (h >> OKPOLY_IDX_BITS);
-        }
-        float s_prev = 0.F;
-        bool  first  = true;
-        for (; k < k_end; k += 2)
+        OkCellHdr hc = h;
+        while (true) // one pass per chunk of <= 32 slots; almost every cell is a single chunk
         {
-            const OkPointPair pp = *reinterpret_cast<const OkPointPair *>(&v.slots[k]);
-            const float       sa = ok_side(pp.a, ox, oy, rdx, rdy);
-            const float       sb = ok_side(pp.b, ox, oy, rdx, rdy);
-            s_prev               = first ? sa : s_prev; // the cell's first slot has no predecessor
-            first                = false;
-            const bool ka        = !ok_same_side(s_prev, sa, tol);
-            const bool kb        = !ok_same_side(sa, sb, tol);
-            if (ka | kb)
-            {
-                if (ka)
-                    st = okPark<kCount>(v, k - 1U, st, ox, oy, rdx, rdy, tests);
-                if (kb)
-                    st = okPark<kCount>(v, k, st, ox, oy, rdx, rdy, tests);
-            }
-            s_prev = sb;
-        }
-        // exact tests of the segments parked in this cell
-        while (st.p0 != OKPOLY_NONE)
-        {
+            const uint32_t k0 = hc.w0 & OKPOLY_IDX_MASK;
+            const uint32_t n  = (hc.w0 >> OKPOLY_IDX_BITS) & OKPOLY_N_MASK;
             if (kCount)
-                *tests += 1;
-            st.min_t = okExactSlot(v, st.p0, ox, oy, rdx, rdy, st.min_t);
-            st.p0    = st.p1;
-            st.p1    = OKPOLY_NONE;
+                *points += n;
+            // Point loop: branch-free.  Bit j of `surv` = the pair (slot k0+j-1, slot k0+j) survived the side rule.
+            uint32_t surv   = 0U;
+            float    s_prev = 0.F;
+            for (uint32_t i = 0; i < n; i += 2)
+            {
+                const OkPointPair pp = *reinterpret_cast<const OkPointPair *>(&v.slots[k0 + i]);
+                const float       sa = ok_side(pp.a, ox, oy, rdx, rdy);
+                const float       sb = ok_side(pp.b, ox, oy, rdx, rdy);
+                s_prev               = (i == 0U) ? sa : s_prev; // the chunk's first slot has no predecessor (brk bit 0)
+                const uint32_t m     = (ok_same_side(s_prev, sa, tol) ? 0U : 1U) | (ok_same_side(sa, sb, tol) ? 0U : 2U);
+                surv |= m << i;
+                s_prev = sb;
+            }
+            // Exact tests of the surviving segments, all lanes of a wave together: the long, division-heavy test stays
+            // out of the point loop, and a wave runs it max-over-lanes(survivors) times per cell (typically 2: the inner
+            // and the outer boundary).  Order does not matter: min is order independent.
+            surv &= ~hc.brk;
+            while (surv != 0U)
+            {
+                const uint32_t j = okCountTrailingZeros(surv);
+                surv &= surv - 1U;
+                if (kCount)
+                    *tests += 1;
+                min_t = okExactSlot(v, k0 + j - 1U, ox, oy, rdx, rdy, min_t);
+            }
+            if (((hc.w0 >> (OKPOLY_IDX_BITS + 6)) & 1U) == 0U)
+                break;
+            hc = *reinterpret_cast<const OkCellHdr *>(&v.slots[k0 + n]);
         }
         const float t_exit = w.exitT();
-        if (__builtin_fminf(st.min_t, w.t_out) <= t_exit)
-            return {st.min_t, t_exit, true};
+        if (__builtin_fminf(min_t, w.t_out) <= t_exit)
+            return {min_t, t_exit, true};
         if (t_exit >= t_b)
-            return {st.min_t, t_exit, false};
+            return {min_t, t_exit, false};
         if (!w.advance(g))
-            return {st.min_t, OK_SENSOR_RANGE, true};
+            return {min_t, OK_SENSOR_RANGE, true};
         h = h_next;
     }
-    return {st.min_t, OK_SENSOR_RANGE, true};
+    return {min_t, OK_SENSOR_RANGE, true};
 }
 
 // First-hit parameter of one whole ray, compact form.

@@ -167,7 +167,6 @@ OkStepParams baseParams(okenv *h)
     p.image         = static_cast<const uint8_t *>(h->d_image);
     p.image_bytes   = static_cast<uint32_t>(h->image_bytes);
     p.off_hdr       = static_cast<uint32_t>(h->poly.off_hdr);
-    p.off_brk       = static_cast<uint32_t>(h->poly.off_brk);
     p.side_tol      = h->poly.side_tol;
     p.geom          = h->grid.g;
     p.g_segs        = h->d_segs;

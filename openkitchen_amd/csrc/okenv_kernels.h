@@ -16,7 +16,7 @@
 //     min over rays of the squared hit distance -- the crash test -- is a xor-shuffle reduction inside
 //     those G lanes, no LDS, no atomics.
 //   * the track is staged ONCE per workgroup into LDS as the compact "poly" image of ok_grid.h: a cell-major
-//     stream of boundary points (8 B each, shared by chained segments) + a 4-byte header per grid cell,
+//     stream of boundary points (8 B each, shared by chained segments) + an 8-byte header per grid cell,
 //     90-115 KB for the config tracks; every point evaluation and ray-segment test then reads LDS,
 //     never HBM.  Adjacent rays of a fan start in the same cell and fan out slowly, so most LDS reads of a
 //     wave-instruction hit the same few addresses (broadcast).
@@ -61,9 +61,9 @@ struct OkStepParams
     int           rays_per_lane;
     const float  *ray_deg;  // [R]
     float         sensor_offset;
-    // compact image in global memory: [slots | hdr | brk], byte offsets from `image` (ok_grid.h)
+    // compact image in global memory: [slots | hdr], byte offsets from `image` (ok_grid.h)
     const uint8_t *image;
-    uint32_t       image_bytes, off_hdr, off_brk;
+    uint32_t       image_bytes, off_hdr;
     float          side_tol;
     OkGridGeom     geom;
     // wide (global-memory) form
@@ -383,8 +383,7 @@ __device__ __forceinline__ OkPolyView okSetupView(const OkStepParams &p, unsigne
         okStageImage(p, lds);
         view.g        = p.geom;
         view.slots    = reinterpret_cast<const OkPoint *>(lds);
-        view.hdr      = reinterpret_cast<const uint32_t *>(lds + p.off_hdr);
-        view.brk      = reinterpret_cast<const uint32_t *>(lds + p.off_brk);
+        view.hdr      = reinterpret_cast<const OkCellHdr *>(lds + p.off_hdr);
         view.side_tol = p.side_tol;
     }
     return view;
@@ -966,8 +965,7 @@ okDebugCastKernel(const OkStepParams p, const float *ox, const float *oy, const 
         okStageImage(p, ok_lds);
         view.g        = p.geom;
         view.slots    = reinterpret_cast<const OkPoint *>(ok_lds);
-        view.hdr      = reinterpret_cast<const uint32_t *>(ok_lds + p.off_hdr);
-        view.brk      = reinterpret_cast<const uint32_t *>(ok_lds + p.off_brk);
+        view.hdr      = reinterpret_cast<const OkCellHdr *>(ok_lds + p.off_hdr);
         view.side_tol = p.side_tol;
     }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)

@@ -39,8 +39,7 @@ extern "C"
                 return -1;
             pv.g        = gh.g;
             pv.slots    = reinterpret_cast<const OkPoint *>(img.bytes.data());
-            pv.hdr      = reinterpret_cast<const uint32_t *>(img.bytes.data() + img.off_hdr);
-            pv.brk      = reinterpret_cast<const uint32_t *>(img.bytes.data() + img.off_brk);
+            pv.hdr      = reinterpret_cast<const OkCellHdr *>(img.bytes.data() + img.off_hdr);
             pv.side_tol = img.side_tol;
         }
         if (info)
