@@ -44,11 +44,7 @@
 /* Environment/CollisionChecker.cu:23 */
 #define OK_PARALLEL_EPS 1e-8f
 
-#if defined(__HIP_DEVICE_COMPILE__)
-#define OK_RINT(x) __builtin_rint(x)
-#else
-#define OK_RINT(x) __builtin_rint(x)
-#endif
+#define OK_RINT(x) __builtin_rint(x) /* round to nearest even: rint() on the host, v_rndne_f64 on gfx950 */
 
 /*
  * sin and cos of an fp32 angle [rad], each correctly rounded from an fp64 evaluation whose error is

@@ -53,7 +53,7 @@ struct okenv
     float      *d_ray_deg{nullptr};
     float       sensor_offset{0.F};
     float      *d_cx{nullptr}, *d_cy{nullptr}, *d_chead{nullptr};
-    int         P{0};
+    int         P{0}, centerline_capacity{0};
     OkDeviceState st{};
     std::vector<void *> allocations;
     int         block_threads{1024}, grid_blocks{1};
@@ -305,8 +305,13 @@ extern "C"
         if (device < 0 || device >= ndev)
             return fail(nullptr, OKENV_ERR_INVALID, "okenv_create: device ordinal out of range");
 
-        std::unique_ptr<okenv> hp(new okenv);
-        okenv                 *h = hp.get();
+        // every early return below releases what has been allocated so far (stream, device buffers)
+        struct Destroy
+        {
+            void operator()(okenv *e) const { okenv_destroy(e); }
+        };
+        std::unique_ptr<okenv, Destroy> hp(new okenv);
+        okenv                          *h = hp.get();
         h->device                = device;
         h->N                     = num_agents;
         h->R                     = num_rays;
@@ -483,9 +488,13 @@ extern "C"
             return fail(h, OKENV_ERR_INVALID, "okenv_set_centerline: bad argument");
         OK_HIP(h, hipSetDevice(h->device));
         int rc;
-        if ((rc = devAlloc(h, &h->d_cx, static_cast<size_t>(num_points))) || (rc = devAlloc(h, &h->d_cy, static_cast<size_t>(num_points))) ||
-            (rc = devAlloc(h, &h->d_chead, static_cast<size_t>(num_points))))
-            return rc;
+        if (num_points > h->centerline_capacity)
+        { // grow only: repeated calls with the same track reuse the buffers
+            if ((rc = devAlloc(h, &h->d_cx, static_cast<size_t>(num_points))) || (rc = devAlloc(h, &h->d_cy, static_cast<size_t>(num_points))) ||
+                (rc = devAlloc(h, &h->d_chead, static_cast<size_t>(num_points))))
+                return rc;
+            h->centerline_capacity = num_points;
+        }
         h->P = num_points;
         h->host_cx.resize(num_points), h->host_cy.resize(num_points), h->host_chead.resize(num_points);
         OK_HIP(h, hipMemcpy(h->host_cx.data(), x, 4U * num_points, hipMemcpyDefault));

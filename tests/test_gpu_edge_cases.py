@@ -85,3 +85,20 @@ def test_population_beyond_uint16(gpu, oracle):
     d, o = dev.snapshot(), orc.snapshot()
     for k in ("pos_x", "pos_y", "crashed", "dist"):
         assert np.array_equal(bits(d[k]), bits(o[k])), k
+
+
+def test_pybind_compat_single_agent(gpu):
+    """The `open_kitchen_pybind.Environment` surface (reference Pybind/bindings.cpp:70-78) over the device environment."""
+    import openkitchen_amd.pybind_compat as okpy
+
+    env = okpy.Environment(gpu.track_path("Austin"), draw_rays=False, hidden_window=True, seed=5)
+    x0, y0, _ = env.pose
+    for _ in range(25):
+        env.step()
+        env.set_action(30.0, 0.0)
+    x1, y1, _ = env.pose
+    assert (x1 - x0) ** 2 + (y1 - y0) ** 2 > 25.0  # ~0.48 px per step at speed 30
+    assert env.distances.shape == (15,) and (env.distances > 0).all() and (env.distances <= 200.0 + 1e-3).all()
+    info = env.get_render_target_info()
+    assert (info.height, info.width, info.channels) == (1400, 1600, 4) and len(env.get_render_target()) == info.height * info.row_bytes()
+    assert isinstance(env.crashed, bool)
