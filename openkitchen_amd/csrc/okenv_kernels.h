@@ -210,8 +210,11 @@ __device__ __forceinline__ void okStoreAgent(const OkDeviceState &st, const int 
 }
 
 // Everything Environment::step does to one agent BEFORE the collision pass (Environment.cpp:128-142), preceded by
-// the optional bench driver (reset of crashed agents + Philox action).
-__device__ __forceinline__ void okAgentPreStep(const OkStepParams &p, OkAgentRegs &r, const int a, const int s)
+// the optional bench driver (reset of crashed agents + Philox action).  Also returns
+// sin/cos(kDeg2Rad * rot_) of the pose the collision pass will see: Agent::move, the ray build and the hit transform
+// all take the sine and cosine of that same angle (Agent.cpp:94-97, CollisionChecker.cu:121-124,157-158), so it is
+// evaluated once per agent and step.
+__device__ __forceinline__ void okAgentPreStep(const OkStepParams &p, OkAgentRegs &r, const int a, const int s, float &sn, float &cs)
 {
     if (p.action_source == kActionsPhiloxReset)
     {
@@ -232,15 +235,15 @@ __device__ __forceinline__ void okAgentPreStep(const OkStepParams &p, OkAgentReg
         r.thr   = ra.throttle;
         r.steer = ra.steer;
     }
-    if (p.do_move && !r.crashed)
+    const bool moves = p.do_move && !r.crashed && (r.mode == 0 || r.mode == 1); // MANUAL: empty in the reference
+    if (moves)
     {
-        bool moved = true;
         if (r.mode == 0)
         { // moveViaVelocity (Agent.cpp:108-119)
             r.rot += r.steer;
             r.speed = r.thr;
         }
-        else if (r.mode == 1)
+        else
         { // moveViaAcceleration (Agent.cpp:82-98)
             r.rot += r.steer;
             r.acc += r.thr;
@@ -248,19 +251,17 @@ __device__ __forceinline__ void okAgentPreStep(const OkStepParams &p, OkAgentReg
             r.speed = (r.speed < 0.F) ? 0.F : r.speed;
             r.speed = (r.speed > OK_SPEED_LIMIT) ? OK_SPEED_LIMIT : r.speed;
         }
-        else
-        {
-            moved = false; // MANUAL: empty in the reference
-        }
-        if (moved)
-        {
-            float sn, cs;
-            ok_sincosf(OK_DEG2RAD * r.rot, &sn, &cs);
-            const float dx = cs * r.speed * OK_DT;
-            r.pos_x += dx;
-            const float dy = sn * r.speed * OK_DT;
-            r.pos_y += dy;
-        }
+    }
+    ok_sincosf(OK_DEG2RAD * r.rot, &sn, &cs);
+    if (moves)
+    {
+        const float dx = cs * r.speed * OK_DT;
+        r.pos_x += dx;
+        const float dy = sn * r.speed * OK_DT;
+        r.pos_y += dy;
+    }
+    if (p.do_move && !r.crashed)
+    {
         // checkAndUpdateStandstill (Environment.cpp:16-39)
         if (r.disp_ctr == 0U)
         {
@@ -413,10 +414,9 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
     {
         if (kPolicy == kPolicyMlp)
             okPolicyAction(p, a, rlane, G, ag, last_dist, pol_ray);
-        okAgentPreStep(p, ag, a, s);
-        // ---- collision pass (CollisionChecker.cu:113-174) ------------------------------------------------
         float sr, cr;
-        ok_sincosf(OK_DEG2RAD * ag.rot, &sr, &cr);
+        okAgentPreStep(p, ag, a, s, sr, cr);
+        // ---- collision pass (CollisionChecker.cu:113-174) ------------------------------------------------
         const float ox     = ag.pos_x + p.sensor_offset * cr;
         const float oy     = ag.pos_y + p.sensor_offset * sr;
         const bool  active = !ag.crashed;
@@ -552,9 +552,8 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
                                                   p.q_epsilon, q0, q1, q2);
             ok_q_action_values(q_action, &ag.thr, &ag.steer);
         }
-        okAgentPreStep(p, ag, a, s);
         float sr, cr;
-        ok_sincosf(OK_DEG2RAD * ag.rot, &sr, &cr);
+        okAgentPreStep(p, ag, a, s, sr, cr);
         const float ox     = ag.pos_x + p.sensor_offset * cr;
         const float oy     = ag.pos_y + p.sensor_offset * sr;
         const bool  casts  = ray_ok && !ag.crashed;
