@@ -127,9 +127,13 @@ OKRC_HD bool ok_ray_segment(const float ox,
     const float denom = rdx * sdy - rdy * sdx;
     if (__builtin_fabsf(denom) < OK_PARALLEL_EPS)
         return false;
+    // Same four comparisons as the reference, evaluated t-first: a candidate beyond the current first hit (the outer
+    // boundary behind the inner one, typically) is dropped before its second division.  The accepted set is identical.
     const float t = ((sx1 - ox) * sdy - (sy1 - oy) * sdx) / denom;
+    if (!((t >= 0.0F) && (t <= range)))
+        return false;
     const float s = ((sx1 - ox) * rdy - (sy1 - oy) * rdx) / denom;
-    if ((t >= 0.0F) && (t <= range) && (s >= 0.0F) && (s <= 1.0F))
+    if ((s >= 0.0F) && (s <= 1.0F))
     {
         t_out = t;
         return true;
