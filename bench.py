@@ -301,13 +301,19 @@ def main():
         steps_per_launch_avg = args.steps / max(launches, 1)
         bytes_per_launch = b_alg * N * steps_per_launch_avg
         achieved_gbs = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        traffic = None
-        try:  # measured HBM bytes per launch from the committed PMC profile, if it matches this configuration
+        traffic, valu = None, None
+        try:  # measured HBM bytes and VALU instructions per launch from the committed PMC profile, if the configuration matches
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
             if (tj["agents"], tj["rays"], tj["track"], tj["steps_per_launch"]) == (N, R, args.track, spl):
                 traffic = tj["hbm_bytes_per_launch"]
+                # the bound that actually binds: VALU issue.  One wave64 VALU instruction per 4 cycles per SIMD, 1024 SIMDs,
+                # 2.4 GHz peak clock; instructions from PMC (profile build of the same kernel), time from this run's HIP events
+                avg_s = (kernel_ms * 1e-3) / max(launches, 1)
+                valu = {"bound": "valu-issue", "insts_per_launch": tj["valu_insts_per_launch"], "cycles_per_inst": 4, "simds": 1024,
+                        "clock_ghz": 2.4, "frac": tj["valu_insts_per_launch"] * 4.0 / (1024 * avg_s * 2.4e9) if avg_s > 0 else None,
+                        "source": tj["source"]}
         except Exception:
-            traffic = None
+            traffic, valu = None, None
         result = {
             "metric": "agent-steps/sec",
             "value": value,
@@ -327,6 +333,7 @@ def main():
                        "global_agents": total_agents, "steps_per_launch": spl, "parallelism": "dp%d (agent shards, no collective)" % world,
                        "grid_cell": info["grid_cell"], "lds_bytes": info["lds_bytes"]},
             "rays_per_sec": value * R,
+            "valu_roofline": valu,
             "value_one_launch_per_step": (N * one_steps / one_elapsed) if one_steps else None,
             "value_host_boundary_pcie_inclusive": (N * pcie_steps / pcie_elapsed) if pcie_steps else None,
             "crashed_fraction_at_end": crashed_frac,

@@ -150,13 +150,25 @@ __device__ __forceinline__ float okCastRay(const OkStepParams &p,
     }
 }
 
-// Stage the compact grid image into LDS with 16-byte loads (image_bytes is a multiple of 16).
+// Stage the compact grid image into LDS with 16-byte loads (image_bytes is a multiple of 16).  Four loads are issued
+// back to back before their stores so that the L2 round trips overlap: with one launch per Environment step the
+// staging is a visible part of the launch.
 __device__ __forceinline__ void okStageImage(const OkStepParams &p, unsigned char *lds)
 {
     const uint4 *src = reinterpret_cast<const uint4 *>(p.image);
     uint4       *dst = reinterpret_cast<uint4 *>(lds);
     const int    n16 = static_cast<int>(p.image_bytes >> 4);
-    for (int i = threadIdx.x; i < n16; i += blockDim.x)
+    const int    bd  = static_cast<int>(blockDim.x);
+    int          i   = static_cast<int>(threadIdx.x);
+    for (; i + 3 * bd < n16; i += 4 * bd)
+    {
+        const uint4 a = src[i], b = src[i + bd], c = src[i + 2 * bd], d = src[i + 3 * bd];
+        dst[i]          = a;
+        dst[i + bd]     = b;
+        dst[i + 2 * bd] = c;
+        dst[i + 3 * bd] = d;
+    }
+    for (; i < n16; i += bd)
         dst[i] = src[i];
     __syncthreads();
 }
