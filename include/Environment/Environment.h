@@ -35,6 +35,8 @@ struct DisplacementStats
 class OKENV_CLASS Environment
 {
   public:
+    // ---- construction -----------------------------------------------------------------------------------------
+    // current surface: the population is fixed at construction (reference Environment/Environment.h:31-34)
     Environment(const std::string          &race_track_path,
                 const std::vector<Agent *> &agents,
                 const bool                  draw_rays     = true,
@@ -42,44 +44,38 @@ class OKENV_CLASS Environment
     // legacy surface: agents are registered afterwards with setAgent(); device buffers are (re)built lazily at the
     // next step() because the ray count is unknown until then
     explicit Environment(const std::string &race_track_path);
+    void     setAgent(Agent *agent);
     ~Environment();
 
-    void setAgent(Agent *agent);
-
-    // no-op without a window (kept for source compatibility)
-    void drawSensorRanges(const std::vector<Vec2d> &sensor_hits);
-
+    // ---- the step ---------------------------------------------------------------------------------------------
     // One Environment step for every registered agent: Agent::move + standstill check for agents that have not
-    // crashed, then the collision pass for all of them, then (headless) render.
+    // crashed, then the collision pass for all of them, then (headless) render.  One fused HIP launch.
     void step();
 
-    int32_t pickRandomResetTrackIdx() const;
-
+    // ---- resets -----------------------------------------------------------------------------------------------
     // Resets the agent onto the track: the start point (index 3) or, if pick_random_point, a random centre-line
     // point, optionally at a random lateral position between the inner boundaries and with a heading offset of
     // +-(45..90) degrees alternating in sign.
-    void resetAgent(Agent     *agent,
-                    const bool pick_random_point = true,
-                    const bool randomize_lane    = false,
-                    const bool randomize_heading = false);
-
-    bool isEnterPressed() const;
-    void saveImage(const std::string &filename) const;
-
-    std::vector<uint8_t>            getRenderTargetHost() const { return screen_grabber_->getRenderTargetHost(); }
-    ScreenGrabber::RenderTargetInfo getRenderTargetInfo() const { return screen_grabber_->getRenderTargetInfo(); }
-
+    void    resetAgent(Agent *agent, const bool pick_random_point = true, const bool randomize_lane = false, const bool randomize_heading = false);
+    int32_t pickRandomResetTrackIdx() const;
     // Seeds the generator behind pickRandomResetTrackIdx / resetAgent (the reference uses raylib's unseeded
     // GetRandomValue; here runs are reproducible).
     static void seedRandom(uint32_t seed);
     static int  randomValue(int lo, int hi); // uniform integer in [lo, hi]
 
+    // ---- window-related members kept for source compatibility (headless here) --------------------------------------
+    void drawSensorRanges(const std::vector<Vec2d> &sensor_hits);
+    bool isEnterPressed() const;
+    void saveImage(const std::string &filename) const;
+    std::vector<uint8_t>            getRenderTargetHost() const { return screen_grabber_->getRenderTargetHost(); }
+    ScreenGrabber::RenderTargetInfo getRenderTargetInfo() const { return screen_grabber_->getRenderTargetInfo(); }
+
   public:
-    std::unique_ptr<RaceTrack>        race_track_;
-    std::unique_ptr<TrackSegments>    track_segments_;
-    std::unique_ptr<env::Visualizer>  visualizer_;
-    std::vector<Agent *>              agents_;
-    std::vector<DisplacementStats>    displacement_stats_;
+    std::unique_ptr<RaceTrack>        race_track_;         // geometry; callers read track_data_points_ / headings_
+    std::unique_ptr<TrackSegments>    track_segments_;     // the 4P boundary segments
+    std::unique_ptr<env::Visualizer>  visualizer_;         // headless stub (user_draw_callback_ still fires)
+    std::vector<Agent *>              agents_;             // not owned
+    std::vector<DisplacementStats>    displacement_stats_; // one per agent, NOT touched by resets
     std::unique_ptr<CollisionChecker> collision_checker_{nullptr};
     std::unique_ptr<ScreenGrabber>    screen_grabber_{nullptr};
 
