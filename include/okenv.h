@@ -215,6 +215,14 @@ OKENV_API int okenv_q_set_table(okenv_t h, const float *in);
 /* current_state_idx_, current_action_idx_, prev_track_idx_ per agent (host arrays, any may be NULL) */
 OKENV_API int okenv_q_get_state(okenv_t h, int32_t *state, int32_t *action, int32_t *prev_idx);
 
+/* shareCumulativeKnowledge (q_racer_sim.cpp:24-75; off by default in the reference, :16): `okenv_q_table_sums` gives, per
+ * (state, action), the sum of the valid entries over this handle's agents and their count (729 floats each, host or
+ * device pointers); `okenv_q_assign_mean` sets every agent's table to sum/count (entries with count 0 stay invalid).  A
+ * multi-GPU caller all-reduces the two vectors between the calls (5.8 KB); `okenv_q_share_knowledge` does both locally. */
+OKENV_API int okenv_q_table_sums(okenv_t h, float *sum, float *count);
+OKENV_API int okenv_q_assign_mean(okenv_t h, const float *sum, const float *count);
+OKENV_API int okenv_q_share_knowledge(okenv_t h);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 
 /* When enabled, every step/collide/rollout launch is bracketed by HIP events on the handle's stream. */

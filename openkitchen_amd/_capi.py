@@ -35,6 +35,7 @@ SYMBOLS = [
     "okenv_policy_mlp_weights_per_agent", "okenv_policy_mlp_get_weights", "okenv_policy_mlp_set_weights",
     "okenv_rollout_policy", "okenv_alive_count", "okenv_reset_all", "okenv_ga_scores", "okenv_ga_select_mate",
     "okenv_q_create", "okenv_q_begin_episode", "okenv_rollout_q", "okenv_q_get_table", "okenv_q_set_table", "okenv_q_get_state",
+    "okenv_q_table_sums", "okenv_q_assign_mean", "okenv_q_share_knowledge",
 ]
 
 
@@ -126,6 +127,9 @@ def load(build_if_missing=True):
     L.okenv_q_get_table.argtypes = [vp, vp]
     L.okenv_q_set_table.argtypes = [vp, vp]
     L.okenv_q_get_state.argtypes = [vp, vp, vp, vp]
+    L.okenv_q_table_sums.argtypes = [vp, vp, vp]
+    L.okenv_q_assign_mean.argtypes = [vp, vp, vp]
+    L.okenv_q_share_knowledge.argtypes = [vp]
     _lib = L
     return L
 

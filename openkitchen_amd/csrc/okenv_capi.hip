@@ -64,6 +64,7 @@ struct okenv
     // Q-learning state
     float   *d_q_table{nullptr};
     int32_t *d_q_state{nullptr}, *d_q_action{nullptr}, *d_q_prev{nullptr}, *d_q_reset_nearest{nullptr};
+    float   *d_q_sums{nullptr};
     int      q_ray[5]{0, 0, 0, 0, 0};
     float    q_epsilon{0.F};
     std::vector<float> host_cx, host_cy, host_chead, host_ray_deg;
@@ -1012,6 +1013,74 @@ extern "C"
             return rc;
         OK_HIP(h, hipStreamSynchronize(h->stream));
         return OKENV_OK;
+    }
+
+    static int qSums(okenv_t h, float **d_out)
+    {
+        if (!h || !h->d_q_table)
+            return fail(h, OKENV_ERR_STATE, "no Q table (call okenv_q_create first)");
+        OK_HIP(h, hipSetDevice(h->device));
+        if (!h->d_q_sums)
+        {
+            int rc = devAlloc(h, &h->d_q_sums, 2U * OK_Q_STATES * OK_Q_ACTIONS);
+            if (rc != OKENV_OK)
+                return rc;
+        }
+        constexpr int kEntries = OK_Q_STATES * OK_Q_ACTIONS;
+        hipLaunchKernelGGL(okQTableSumsKernel, dim3((kEntries + 63) / 64), dim3(64), 0, h->stream, h->d_q_table, h->N, h->d_q_sums,
+                           h->d_q_sums + kEntries);
+        OK_HIP(h, hipGetLastError());
+        *d_out = h->d_q_sums;
+        return OKENV_OK;
+    }
+
+    int okenv_q_table_sums(okenv_t h, float *sum, float *count)
+    {
+        if (!sum || !count)
+            return fail(h, OKENV_ERR_INVALID, "okenv_q_table_sums: NULL argument");
+        float *d  = nullptr;
+        int    rc = qSums(h, &d);
+        if (rc != OKENV_OK)
+            return rc;
+        constexpr size_t kBytes = sizeof(float) * OK_Q_STATES * OK_Q_ACTIONS;
+        if ((rc = copyAny(h, sum, d, kBytes)) || (rc = copyAny(h, count, d + OK_Q_STATES * OK_Q_ACTIONS, kBytes)))
+            return rc;
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        return OKENV_OK;
+    }
+
+    int okenv_q_assign_mean(okenv_t h, const float *sum, const float *count)
+    {
+        if (!h || !h->d_q_table || !sum || !count)
+            return fail(h, OKENV_ERR_STATE, "okenv_q_assign_mean: no Q table or NULL argument");
+        OK_HIP(h, hipSetDevice(h->device));
+        if (!h->d_q_sums)
+        {
+            int rc = devAlloc(h, &h->d_q_sums, 2U * OK_Q_STATES * OK_Q_ACTIONS);
+            if (rc != OKENV_OK)
+                return rc;
+        }
+        constexpr int    kEntries = OK_Q_STATES * OK_Q_ACTIONS;
+        constexpr size_t kBytes   = sizeof(float) * kEntries;
+        int              rc;
+        if ((sum != h->d_q_sums && (rc = copyAny(h, h->d_q_sums, sum, kBytes))) ||
+            (count != h->d_q_sums + kEntries && (rc = copyAny(h, h->d_q_sums + kEntries, count, kBytes))))
+            return rc;
+        const long total = static_cast<long>(h->N) * kEntries;
+        hipLaunchKernelGGL(okQAssignAllKernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, h->stream, h->d_q_table, h->N,
+                           h->d_q_sums, h->d_q_sums + kEntries);
+        OK_HIP(h, hipGetLastError());
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        return OKENV_OK;
+    }
+
+    int okenv_q_share_knowledge(okenv_t h)
+    {
+        float *d  = nullptr;
+        int    rc = qSums(h, &d);
+        if (rc != OKENV_OK)
+            return rc;
+        return okenv_q_assign_mean(h, d, d + OK_Q_STATES * OK_Q_ACTIONS);
     }
 
     int okenv_set_timing(okenv_t h, int32_t enabled)

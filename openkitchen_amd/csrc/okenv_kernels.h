@@ -958,6 +958,39 @@ __global__ void okQBeginEpisodeKernel(const float *dist, int R, int r0, int r1, 
     q_prev[a]      = reset_nearest[0];
 }
 
+// shareCumulativeKnowledge (q_racer_sim.cpp:24-75), first half: per (state, action) the sum of the VALID entries over the
+// agents, accumulated in agent order like the reference's loop, and their count.  One thread per table entry.
+__global__ void okQTableSumsKernel(const float *q, int N, float *sum, float *count)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= OK_Q_STATES * OK_Q_ACTIONS)
+        return;
+    float total = OK_Q_INVALID, cnt = 0.F;
+    for (int a = 0; a < N; ++a)
+    {
+        const float v = q[static_cast<size_t>(a) * (OK_Q_STATES * OK_Q_ACTIONS) + e];
+        if (v != OK_Q_INVALID)
+        {
+            if (total == OK_Q_INVALID)
+                total = 0.F;
+            total += v;
+            cnt += 1.F;
+        }
+    }
+    sum[e]   = total;
+    count[e] = cnt;
+}
+
+// second half: every agent's table becomes the mean (or stays invalid where nobody has a value yet)
+__global__ void okQAssignAllKernel(float *q, int N, const float *sum, const float *count)
+{
+    const long t = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= static_cast<long>(N) * (OK_Q_STATES * OK_Q_ACTIONS))
+        return;
+    const int e = static_cast<int>(t % (OK_Q_STATES * OK_Q_ACTIONS));
+    q[t]        = (count[e] > 0.F) ? sum[e] / count[e] : sum[e];
+}
+
 __global__ void okDebugSincosKernel(const float *x, float *s, float *c, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

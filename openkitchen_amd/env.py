@@ -240,6 +240,19 @@ class BatchedEnvironment:
         capi.check(self._L.okenv_q_get_state(self._h, capi.ptr(s), capi.ptr(a), capi.ptr(p)), self._h)
         return s, a, p
 
+    def q_table_sums(self):
+        s, c = np.zeros(729, dtype=np.float32), np.zeros(729, dtype=np.float32)
+        capi.check(self._L.okenv_q_table_sums(self._h, capi.ptr(s), capi.ptr(c)), self._h)
+        return s, c
+
+    def q_assign_mean(self, sums, counts):
+        s = np.ascontiguousarray(sums, dtype=np.float32)
+        c = np.ascontiguousarray(counts, dtype=np.float32)
+        capi.check(self._L.okenv_q_assign_mean(self._h, capi.ptr(s), capi.ptr(c)), self._h)
+
+    def q_share_knowledge(self):
+        capi.check(self._L.okenv_q_share_knowledge(self._h), self._h)
+
     # ---- measurement / self-checks ------------------------------------------------------------------
     def set_timing(self, enabled):
         capi.check(self._L.okenv_set_timing(self._h, 1 if enabled else 0), self._h)

@@ -55,3 +55,37 @@ def test_q_state_rays_for_wide_fans(gpu):
     small = gpu.BatchedEnvironment(t.segments, 4, gpu.default_ray_fan(3), centerline=(t.x, t.y, t.heading))
     with pytest.raises(gpu.capi.OkenvError):
         small.q_create()
+
+
+def test_share_cumulative_knowledge(gpu):
+    """shareCumulativeKnowledge (q_racer_sim.cpp:24-75): every table becomes the agent-order mean of the valid entries;
+    entries nobody has learnt stay invalid.  Checked against a numpy restatement of the reference's loop."""
+    t = gpu.Track("Silverstone")
+    N = 96
+    env = gpu.BatchedEnvironment(t.segments, N, gpu.default_ray_fan(16), centerline=(t.x, t.y, t.heading))
+    env.q_create()
+    env.q_begin_episode(3)
+    env.rollout_q(200, 0.9, 5, 0, 0)
+    before = env.q_table().reshape(N, -1)
+    invalid = np.float32(np.finfo(np.float32).min)
+    want = np.full(before.shape[1], invalid, dtype=np.float32)
+    for e in range(before.shape[1]):
+        total, cnt = invalid, np.float32(0)
+        for a in range(N):
+            v = before[a, e]
+            if v != invalid:
+                total = np.float32(0) if total == invalid else total
+                total = np.float32(total + v)
+                cnt = np.float32(cnt + 1)
+        want[e] = np.float32(total / cnt) if cnt > 0 else total
+    sums, counts = env.q_table_sums()
+    assert (counts > 0).sum() > 5
+    env.q_share_knowledge()
+    after = env.q_table().reshape(N, -1)
+    assert np.array_equal(after.view(np.uint32), np.tile(want.view(np.uint32), (N, 1)))
+    # the two-call form a multi-GPU caller uses around its all-reduce
+    env.set_q_table(before.reshape(N, 243, 3))
+    s2, c2 = env.q_table_sums()
+    assert np.array_equal(s2.view(np.uint32), sums.view(np.uint32)) and np.array_equal(c2, counts)
+    env.q_assign_mean(s2, c2)
+    assert np.array_equal(env.q_table().reshape(N, -1).view(np.uint32), after.view(np.uint32))
