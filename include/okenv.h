@@ -142,6 +142,43 @@ OKENV_API int okenv_set_actions(okenv_t h, const float *throttle, const float *s
 /* Agent::reset (Environment/Agent.cpp:123-135) for agents idx[0..n): pose set, speed/acc/action zeroed,
  * crashed/timed_out cleared; DisplacementStats untouched, as in the reference.  Host arrays. */
 OKENV_API int okenv_reset_agents(okenv_t h, const int32_t *idx, const float *x, const float *y, const float *rot_deg, int32_t n);
+/* ---- device-side Environment::resetAgent ----------------------------- */
+
+/* the booleans of Environment::resetAgent(agent, pick_random_point, randomize_lane, randomize_heading)
+ * (Environment/Environment.h:47-50); values shared with include/okenv_math.h (OK_RESET_*) */
+#define OKENV_RESET_RANDOM_POINT 1u
+#define OKENV_RESET_RANDOM_LANE 2u
+#define OKENV_RESET_RANDOM_HEADING 4u
+#define OKENV_RESET_ONLY_DONE 8u /* batch call only: skip agents whose crashed_ flag is clear */
+
+/* RaceTrack::left_bound_inner_ / right_bound_inner_ (Environment/RaceTrack.h:77) as xy pairs, what the lane
+ * randomisation interpolates between (Environment/Environment.cpp:108-113).  Host or device pointers. */
+OKENV_API int okenv_set_lane_bounds(okenv_t h, const float *left_inner_xy, const float *right_inner_xy, int32_t num_points);
+/* Environment::resetAgent (Environment/Environment.cpp:79-122) for agents idx[0..n) (idx NULL: all agents, n ignored),
+ * on the device.  raylib's GetRandomValue is replaced by Philox4x32 keyed (seed; agent_base + agent, epoch), see
+ * ok_draw_reset in okenv_math.h; entry j of the call takes the reference's static call counter as epoch + j, so a loop
+ * `for (agent : agents) env.resetAgent(agent, ...)` is one call.  idx may be a host or a device pointer.
+ * Without OKENV_RESET_RANDOM_POINT every agent goes to RaceTrack::kStartingIdx with the track heading. */
+OKENV_API int okenv_reset_random(okenv_t h, const int32_t *idx, int32_t n, uint32_t flags, uint32_t seed, uint32_t epoch,
+                                 uint32_t agent_base);
+/* Per-agent auto-reset for continuous training: while enabled, okenv_step and okenv_rollout_policy begin every step
+ * by applying resetAgent(flags) to the agents whose crashed_ flag is set, drawing from Philox (seed; agent_base +
+ * agent, step count) with call-counter parity agent + step count; that step then runs with the zeroed action, i.e.
+ * it is the "initial observation" step callers take after a reset (RLRacers/PPO/ppo_sim.cpp:53-60).  The flags
+ * of the crash stay readable until that next step. */
+OKENV_API int okenv_set_auto_reset(okenv_t h, int32_t enabled, uint32_t flags, uint32_t seed, uint32_t agent_base);
+/* Environment steps taken so far by okenv_step / okenv_rollout_policy on this handle (the auto-reset epoch). */
+OKENV_API int okenv_get_step_count(okenv_t h, uint32_t *out);
+OKENV_API int okenv_set_step_count(okenv_t h, uint32_t value);
+
+/* ---- zero-copy access for device-side callers ------------------------ */
+
+/* Device address and size of one library-owned struct-of-arrays field (okenv_field), valid for the handle's lifetime.
+ * Work on it must be ordered against the handle's stream (okenv_set_stream / okenv_sync).  This is what the batched
+ * Python binding wraps into tensors instead of copying sensor_hits_ / crashed_ out per step the way
+ * Pybind/bindings.cpp:36-52 round-trips one agent. */
+OKENV_API int okenv_field_device_ptr(okenv_t h, int32_t field, void **ptr, uint64_t *bytes);
+
 /* Agent::sensor_hits_ as interleaved (x,y) pairs [N*R*2], Agent::sensor_hits_[r].norm() [N*R], and
  * crashed_/timed_out_ as bit0/bit1 of one byte per agent.  Synchronise. */
 OKENV_API int okenv_get_hits(okenv_t h, float *out_xy);

@@ -158,6 +158,63 @@ OK_HD uint32_t ok_start_index(uint32_t agent, uint32_t P)
     return (uint32_t)(agent * 2654435761u) % P;
 }
 
+/* ---- Environment::resetAgent (Environment/Environment.cpp:79-122) -- */
+
+/* the three booleans of resetAgent(agent, pick_random_point, randomize_lane, randomize_heading) */
+#define OK_RESET_RANDOM_POINT 1u
+#define OK_RESET_RANDOM_LANE 2u
+#define OK_RESET_RANDOM_HEADING 4u
+/* batch calls only: leave agents whose crashed_ flag is clear alone */
+#define OK_RESET_ONLY_DONE 8u
+/* RaceTrack::kStartingIdx (Environment/RaceTrack.h:18) */
+#define OK_RESET_START_IDX 3u
+
+/*
+ * The random draws of one resetAgent call.  raylib's GetRandomValue(lo, hi) (inclusive integer range, un-vendored,
+ * global state) is replaced by one Philox block per (agent, epoch):
+ *   counter = (agent, epoch, 1, 0), key = (seed, 0x6F6B656E)
+ *   word 0 -> reset_idx in [0, P-1]            (Environment.cpp:76)
+ *   word 1 -> heading draw in [0, 45]          (:92)
+ *   word 2 -> lane draw in [10, 90], / 100.F   (:111)
+ * `ctr` stands for the reference's function-static call counter (:88): even calls turn the heading offset negative.
+ * The draws the reference skips (flags off) are simply not used, so one flag does not shift another's stream.
+ */
+typedef struct ok_reset_draw { uint32_t idx; float heading_offset; float alpha; int use_lane; } ok_reset_draw;
+
+OK_HD ok_reset_draw ok_draw_reset(uint32_t seed, uint32_t agent, uint32_t epoch, uint32_t ctr, uint32_t P, uint32_t flags)
+{
+    const ok_u32x4 r = ok_philox4x32(agent, epoch, 1u, 0u, seed, 0x6F6B656Eu);
+    const int random_point = (flags & OK_RESET_RANDOM_POINT) != 0u;
+    ok_reset_draw d;
+    d.idx = random_point ? ok_index_from_word(r.v[0], P) : OK_RESET_START_IDX;
+    d.heading_offset = 0.0f;
+    if (random_point && (flags & OK_RESET_RANDOM_HEADING) != 0u) {
+        const float kHeadingRangeDeg = 45.0f;
+        const float draw = (float)ok_index_from_word(r.v[1], 46u);
+        d.heading_offset = (ctr % 2u == 0u) ? (draw + kHeadingRangeDeg) * -1.0f : draw + kHeadingRangeDeg;
+    }
+    d.use_lane = random_point && (flags & OK_RESET_RANDOM_LANE) != 0u;
+    d.alpha = d.use_lane ? (float)(10u + ok_index_from_word(r.v[2], 81u)) / 100.0f : 0.0f;
+    return d;
+}
+
+/* Pose of the reset (Environment.cpp:104-121): a point between the inner lane boundaries or the centre-line point,
+ * track heading plus the offset.  `li`/`ri` are left_bound_inner_/right_bound_inner_ as xy pairs. */
+OK_HD void ok_reset_pose(const ok_reset_draw d, const float *cx, const float *cy, const float *chead, const float *li,
+                         const float *ri, float *x, float *y, float *rot)
+{
+    if (d.use_lane) {
+        const float lx = li[2u * d.idx], ly = li[2u * d.idx + 1u];
+        const float rx = ri[2u * d.idx], ry = ri[2u * d.idx + 1u];
+        *x = lx * d.alpha + rx * (1.0f - d.alpha);
+        *y = ly * d.alpha + ry * (1.0f - d.alpha);
+    } else {
+        *x = cx[d.idx];
+        *y = cy[d.idx];
+    }
+    *rot = chead[d.idx] + d.heading_offset;
+}
+
 /* ---- EvolutionaryRacer policy ------------------------------- */
 
 /* Weight layout per agent (floats): w1[(R+2)][OK_MLP_HID_PAD] then w2[OK_MLP_HID_PAD][OK_MLP_OUT_PAD]; entries beyond

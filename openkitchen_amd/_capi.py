@@ -14,6 +14,7 @@ OKENV_OK = 0
 ERR_NAMES = {0: "OK", -1: "INVALID", -2: "HIP", -3: "NO_DEVICE", -4: "IO", -5: "STATE"}
 
 MODE_VELOCITY, MODE_ACCELERATION, MODE_MANUAL = 0, 1, 2
+RESET_RANDOM_POINT, RESET_RANDOM_LANE, RESET_RANDOM_HEADING, RESET_ONLY_DONE = 1, 2, 4, 8
 FLAG_NONE, FLAG_FORCE_GLOBAL_GRID, FLAG_BRUTE_FORCE = 0, 1, 2
 
 (F_POS_X, F_POS_Y, F_ROT, F_SPEED, F_ACC, F_THROTTLE, F_STEER, F_MODE, F_CRASHED, F_TIMED_OUT, F_DISP_CTR, F_DISP_X,
@@ -36,6 +37,8 @@ SYMBOLS = [
     "okenv_rollout_policy", "okenv_alive_count", "okenv_reset_all", "okenv_ga_scores", "okenv_ga_select_mate",
     "okenv_q_create", "okenv_q_begin_episode", "okenv_rollout_q", "okenv_q_get_table", "okenv_q_set_table", "okenv_q_get_state",
     "okenv_q_table_sums", "okenv_q_assign_mean", "okenv_q_share_knowledge",
+    "okenv_set_lane_bounds", "okenv_reset_random", "okenv_set_auto_reset", "okenv_get_step_count",
+    "okenv_set_step_count", "okenv_field_device_ptr",
 ]
 
 
@@ -130,6 +133,12 @@ def load(build_if_missing=True):
     L.okenv_q_table_sums.argtypes = [vp, vp, vp]
     L.okenv_q_assign_mean.argtypes = [vp, vp, vp]
     L.okenv_q_share_knowledge.argtypes = [vp]
+    L.okenv_set_lane_bounds.argtypes = [vp, vp, vp, i32]
+    L.okenv_reset_random.argtypes = [vp, vp, i32, u32, u32, u32, u32]
+    L.okenv_set_auto_reset.argtypes = [vp, i32, u32, u32, u32]
+    L.okenv_get_step_count.argtypes = [vp, C.POINTER(u32)]
+    L.okenv_set_step_count.argtypes = [vp, u32]
+    L.okenv_field_device_ptr.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_uint64)]
     _lib = L
     return L
 

@@ -54,6 +54,10 @@ struct okenv
     float       sensor_offset{0.F};
     float      *d_cx{nullptr}, *d_cy{nullptr}, *d_chead{nullptr};
     int         P{0}, centerline_capacity{0};
+    float      *d_lane_l{nullptr}, *d_lane_r{nullptr}; // left_bound_inner_ / right_bound_inner_, xy pairs
+    int         lane_points{0}, lane_capacity{0};
+    uint32_t    reset_flags{0}, reset_seed{0}, reset_agent_base{0}; // okenv_set_auto_reset
+    uint32_t    step_count{0};                                      // Environment steps taken by okenv_step / okenv_rollout_policy
     OkDeviceState st{};
     std::vector<void *> allocations;
     int         block_threads{1024}, grid_blocks{1};
@@ -181,6 +185,12 @@ OkStepParams baseParams(okenv *h)
     p.cy            = h->d_cy;
     p.chead         = h->d_chead;
     p.P             = h->P;
+    p.reset_flags   = h->reset_flags;
+    p.reset_seed    = h->reset_seed;
+    p.agent_base    = h->reset_agent_base;
+    p.step_base     = h->step_count;
+    p.lane_l        = h->d_lane_l;
+    p.lane_r        = h->d_lane_r;
     p.mlp_w         = h->d_mlp_w;
     p.q_table       = h->d_q_table;
     p.q_state       = h->d_q_state;
@@ -631,6 +641,114 @@ extern "C"
         return OKENV_OK;
     }
 
+    int okenv_set_lane_bounds(okenv_t h, const float *left_inner_xy, const float *right_inner_xy, int32_t num_points)
+    {
+        if (!h || !left_inner_xy || !right_inner_xy || num_points <= 0)
+            return fail(h, OKENV_ERR_INVALID, "okenv_set_lane_bounds: bad argument");
+        OK_HIP(h, hipSetDevice(h->device));
+        if (num_points > h->lane_capacity)
+        {
+            int rc;
+            if ((rc = devAlloc(h, &h->d_lane_l, 2U * static_cast<size_t>(num_points))) ||
+                (rc = devAlloc(h, &h->d_lane_r, 2U * static_cast<size_t>(num_points))))
+                return rc;
+            h->lane_capacity = num_points;
+        }
+        h->lane_points = num_points;
+        OK_HIP(h, hipMemcpyAsync(h->d_lane_l, left_inner_xy, 8U * num_points, hipMemcpyDefault, h->stream));
+        OK_HIP(h, hipMemcpyAsync(h->d_lane_r, right_inner_xy, 8U * num_points, hipMemcpyDefault, h->stream));
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        return OKENV_OK;
+    }
+
+    // shared precondition of the two resetAgent entry points
+    static int checkResetInputs(okenv_t h, const uint32_t flags, const char *who)
+    {
+        if (h->P <= 0)
+            return fail(h, OKENV_ERR_STATE, std::string(who) + ": call okenv_set_centerline first");
+        if ((flags & OK_RESET_RANDOM_POINT) == 0U && h->P <= static_cast<int>(OK_RESET_START_IDX))
+            return fail(h, OKENV_ERR_STATE, std::string(who) + ": the centre line is shorter than RaceTrack::kStartingIdx");
+        if ((flags & OK_RESET_RANDOM_POINT) != 0U && (flags & OK_RESET_RANDOM_LANE) != 0U && h->lane_points != h->P)
+            return fail(h, OKENV_ERR_STATE, std::string(who) + ": lane randomisation needs okenv_set_lane_bounds with as many points as the centre line");
+        return OKENV_OK;
+    }
+
+    int okenv_reset_random(okenv_t h, const int32_t *idx, int32_t n, uint32_t flags, uint32_t seed, uint32_t epoch, uint32_t agent_base)
+    {
+        if (!h || n < 0)
+            return fail(h, OKENV_ERR_INVALID, "okenv_reset_random: bad argument");
+        if (!idx)
+            n = h->N;
+        if (n == 0)
+            return OKENV_OK;
+        int rc = checkResetInputs(h, flags, "okenv_reset_random");
+        if (rc != OKENV_OK)
+            return rc;
+        OK_HIP(h, hipSetDevice(h->device));
+        int32_t *didx = nullptr;
+        if (idx)
+        {
+            OK_HIP(h, hipMallocAsync(reinterpret_cast<void **>(&didx), 4U * static_cast<size_t>(n), h->stream));
+            OK_HIP(h, hipMemcpyAsync(didx, idx, 4U * static_cast<size_t>(n), hipMemcpyDefault, h->stream));
+        }
+        hipLaunchKernelGGL(okResetRandomKernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->st, didx, n, h->N, flags, seed, epoch,
+                           agent_base, h->d_cx, h->d_cy, h->d_chead, h->d_lane_l, h->d_lane_r, h->P);
+        OK_HIP(h, hipGetLastError());
+        if (didx)
+        {
+            OK_HIP(h, hipFreeAsync(didx, h->stream));
+            OK_HIP(h, hipStreamSynchronize(h->stream)); // the caller may reuse idx
+        }
+        return OKENV_OK;
+    }
+
+    int okenv_set_auto_reset(okenv_t h, int32_t enabled, uint32_t flags, uint32_t seed, uint32_t agent_base)
+    {
+        if (!h)
+            return OKENV_ERR_INVALID;
+        if (!enabled)
+        {
+            h->reset_flags = 0;
+            return OKENV_OK;
+        }
+        const int rc = checkResetInputs(h, flags, "okenv_set_auto_reset");
+        if (rc != OKENV_OK)
+            return rc;
+        h->reset_flags      = (flags & (OK_RESET_RANDOM_POINT | OK_RESET_RANDOM_LANE | OK_RESET_RANDOM_HEADING)) | kAutoResetOn;
+        h->reset_seed       = seed;
+        h->reset_agent_base = agent_base;
+        return OKENV_OK;
+    }
+
+    int okenv_get_step_count(okenv_t h, uint32_t *out)
+    {
+        if (!h || !out)
+            return fail(h, OKENV_ERR_INVALID, "okenv_get_step_count: NULL argument");
+        *out = h->step_count;
+        return OKENV_OK;
+    }
+
+    int okenv_set_step_count(okenv_t h, uint32_t value)
+    {
+        if (!h)
+            return OKENV_ERR_INVALID;
+        h->step_count = value;
+        return OKENV_OK;
+    }
+
+    int okenv_field_device_ptr(okenv_t h, int32_t field, void **ptr, uint64_t *bytes)
+    {
+        if (!h || !ptr)
+            return fail(h, OKENV_ERR_INVALID, "okenv_field_device_ptr: NULL argument");
+        const FieldDesc d = fieldOf(h, field);
+        if (!d.ptr)
+            return fail(h, OKENV_ERR_INVALID, "okenv_field_device_ptr: unknown field");
+        *ptr = d.ptr;
+        if (bytes)
+            *bytes = d.bytes;
+        return OKENV_OK;
+    }
+
     int okenv_get_hits(okenv_t h, float *out_xy)
     {
         if (!h || !out_xy)
@@ -676,7 +794,10 @@ extern "C"
             return OKENV_OK;
         OkStepParams p = baseParams(h);
         p.n_steps      = n_steps;
-        return launchStep(h, p);
+        const int rc   = launchStep(h, p);
+        if (rc == OKENV_OK)
+            h->step_count += static_cast<uint32_t>(n_steps);
+        return rc;
     }
 
     int okenv_collide(okenv_t h)
@@ -685,6 +806,7 @@ extern "C"
             return OKENV_ERR_INVALID;
         OkStepParams p = baseParams(h);
         p.do_move      = 0;
+        p.reset_flags  = 0;
         return launchStep(h, p);
     }
 
@@ -699,6 +821,7 @@ extern "C"
         OkStepParams p  = baseParams(h);
         p.n_steps       = n_steps;
         p.action_source = kActionsPhiloxReset;
+        p.reset_flags   = 0; // this driver re-places crashed agents itself
         p.seed          = seed;
         p.agent_base    = agent_base;
         p.step_base     = step_base;
@@ -817,7 +940,10 @@ extern "C"
         OkStepParams p  = baseParams(h);
         p.n_steps       = n_steps;
         p.action_source = kActionsMlpPolicy;
-        return launchStep(h, p);
+        const int rc    = launchStep(h, p);
+        if (rc == OKENV_OK)
+            h->step_count += static_cast<uint32_t>(n_steps);
+        return rc;
     }
 
     int okenv_alive_count(okenv_t h, int32_t *out)
@@ -975,6 +1101,7 @@ extern "C"
         OkStepParams p  = baseParams(h);
         p.n_steps       = n_steps;
         p.action_source = kActionsQLearning;
+        p.reset_flags   = 0; // episodes are restarted by okenv_q_begin_episode
         p.seed          = seed;
         p.agent_base    = agent_base;
         p.step_base     = step_base;

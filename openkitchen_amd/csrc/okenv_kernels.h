@@ -78,6 +78,10 @@ struct OkStepParams
     uint32_t seed, agent_base, step_base;
     const float *cx, *cy, *chead;
     int          P;
+    // device-side Environment::resetAgent of crashed agents at the start of a step (okenv_set_auto_reset):
+    // reset_flags = OK_RESET_* | kAutoResetOn, inner lane boundaries as xy pairs [P][2]
+    uint32_t     reset_flags, reset_seed;
+    const float *lane_l, *lane_r;
     // EvolutionaryRacer policy weights, OK_MLP_WEIGHTS(R) floats per agent (layout in okenv_math.h)
     const float *mlp_w;
     // RLRacers/Q_Learning: per-agent table [N][243][3], current state / action / previous track index, the five
@@ -87,6 +91,8 @@ struct OkStepParams
     int      q_ray[5];
     float    q_epsilon;
 };
+
+constexpr uint32_t kAutoResetOn = 0x80000000U;
 
 // Compile-time policy selector of the step kernels, so that the headline path carries no policy registers.
 enum OkPolicyKind : int
@@ -228,6 +234,22 @@ __device__ __forceinline__ void okStoreAgent(const OkDeviceState &st, const int 
 // evaluated once per agent and step.
 __device__ __forceinline__ void okAgentPreStep(const OkStepParams &p, OkAgentRegs &r, const int a, const int s, float &sn, float &cs)
 {
+    if ((p.reset_flags & kAutoResetOn) != 0U && r.crashed)
+    {
+        // Environment::resetAgent (Environment.cpp:79-122) + Agent::reset (Agent.cpp:123-135): the step that follows
+        // runs with the zeroed action, i.e. it is the "initial observation" step the callers take after a reset
+        // (ppo_sim.cpp:58-60, main_eigen.cpp:127-128); DisplacementStats deliberately untouched
+        const uint32_t      ag    = p.agent_base + static_cast<uint32_t>(a);
+        const uint32_t      epoch = p.step_base + static_cast<uint32_t>(s);
+        const ok_reset_draw d     = ok_draw_reset(p.reset_seed, ag, epoch, ag + epoch, static_cast<uint32_t>(p.P), p.reset_flags);
+        ok_reset_pose(d, p.cx, p.cy, p.chead, p.lane_l, p.lane_r, &r.pos_x, &r.pos_y, &r.rot);
+        r.acc       = 0.F;
+        r.speed     = 0.F;
+        r.crashed   = false;
+        r.timed_out = false;
+        r.thr       = 0.F;
+        r.steer     = 0.F;
+    }
     if (p.action_source == kActionsPhiloxReset)
     {
         const ok_random_action ra =
@@ -731,6 +753,46 @@ __global__ void okResetKernel(OkDeviceState st, const int32_t *idx, const float 
     st.pos_x[a]     = x[i];
     st.pos_y[a]     = y[i];
     st.rot[a]       = rot[i];
+    st.acc[a]       = 0.F;
+    st.speed[a]     = 0.F;
+    st.crashed[a]   = 0;
+    st.timed_out[a] = 0;
+    st.thr[a]       = 0.F;
+    st.steer[a]     = 0.F;
+}
+
+// Environment::resetAgent (Environment.cpp:79-122) for a list of agents (idx == nullptr: agents 0..n-1); entry j of the
+// call draws from Philox (agent_base + agent, epoch) and takes call-counter parity epoch + j (okenv_math.h).
+__global__ void okResetRandomKernel(OkDeviceState st,
+                                    const int32_t *idx,
+                                    int            n,
+                                    int            N,
+                                    uint32_t       flags,
+                                    uint32_t       seed,
+                                    uint32_t       epoch,
+                                    uint32_t       agent_base,
+                                    const float   *cx,
+                                    const float   *cy,
+                                    const float   *chead,
+                                    const float   *lane_l,
+                                    const float   *lane_r,
+                                    int            P)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n)
+        return;
+    const int a = idx ? idx[j] : j;
+    if (a < 0 || a >= N)
+        return;
+    if ((flags & OK_RESET_ONLY_DONE) != 0U && st.crashed[a] == 0)
+        return;
+    const ok_reset_draw d = ok_draw_reset(seed, agent_base + static_cast<uint32_t>(a), epoch, epoch + static_cast<uint32_t>(j),
+                                          static_cast<uint32_t>(P), flags);
+    float               x, y, rot;
+    ok_reset_pose(d, cx, cy, chead, lane_l, lane_r, &x, &y, &rot);
+    st.pos_x[a]     = x;
+    st.pos_y[a]     = y;
+    st.rot[a]       = rot;
     st.acc[a]       = 0.F;
     st.speed[a]     = 0.F;
     st.crashed[a]   = 0;

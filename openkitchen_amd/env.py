@@ -74,7 +74,9 @@ class BatchedEnvironment:
     @classmethod
     def from_track(cls, track, num_agents, num_rays=None, ray_angles_deg=None, **kw):
         rays = default_ray_fan(num_rays) if ray_angles_deg is None else ray_angles_deg
-        return cls(track.segments, num_agents, rays, centerline=(track.x, track.y, track.heading), **kw)
+        env = cls(track.segments, num_agents, rays, centerline=(track.x, track.y, track.heading), **kw)
+        env.set_lane_bounds(track.li, track.ri)
+        return env
 
     def close(self):
         if getattr(self, "_h", None):
@@ -97,6 +99,13 @@ class BatchedEnvironment:
         x, y, hd = [np.ascontiguousarray(a, dtype=np.float32) for a in (x, y, heading_deg)]
         self.P = int(x.size)
         capi.check(self._L.okenv_set_centerline(self._h, capi.ptr(x), capi.ptr(y), capi.ptr(hd), self.P), self._h)
+
+    def set_lane_bounds(self, left_inner_xy, right_inner_xy):
+        """RaceTrack::left_bound_inner_ / right_bound_inner_ as xy pairs (resetAgent's lane randomisation)."""
+        l = np.ascontiguousarray(left_inner_xy, dtype=np.float32).reshape(-1)
+        r = np.ascontiguousarray(right_inner_xy, dtype=np.float32).reshape(-1)
+        assert l.size == r.size and l.size % 2 == 0
+        capi.check(self._L.okenv_set_lane_bounds(self._h, capi.ptr(l), capi.ptr(r), l.size // 2), self._h)
 
     def set_sensor_offset(self, off):
         capi.check(self._L.okenv_set_sensor_offset(self._h, float(off)), self._h)
@@ -139,6 +148,41 @@ class BatchedEnvironment:
         x, y, rot = [np.ascontiguousarray(a, dtype=np.float32) for a in (x, y, rot_deg)]
         capi.check(self._L.okenv_reset_agents(self._h, capi.ptr(idx), capi.ptr(x), capi.ptr(y), capi.ptr(rot), idx.size),
                    self._h)
+
+    def reset_random(self, idx=None, flags=capi.RESET_RANDOM_POINT, seed=0, epoch=0, agent_base=0):
+        """Environment::resetAgent on the device for agents `idx` (None: all); flags = capi.RESET_*."""
+        if idx is None:
+            capi.check(self._L.okenv_reset_random(self._h, None, 0, int(flags), int(seed), int(epoch), int(agent_base)),
+                       self._h)
+            return
+        if isinstance(idx, np.ndarray) or not hasattr(idx, "data_ptr"):
+            idx = np.ascontiguousarray(idx, dtype=np.int32)
+            n = idx.size
+        else:
+            n = idx.numel()
+        capi.check(self._L.okenv_reset_random(self._h, capi.ptr(idx), int(n), int(flags), int(seed), int(epoch),
+                                              int(agent_base)), self._h)
+
+    def set_auto_reset(self, enabled, flags=capi.RESET_RANDOM_POINT, seed=0, agent_base=0):
+        """While on, every step begins by re-placing the agents whose crashed_ flag is set (include/okenv.h)."""
+        capi.check(self._L.okenv_set_auto_reset(self._h, int(bool(enabled)), int(flags), int(seed), int(agent_base)),
+                   self._h)
+
+    @property
+    def step_count(self):
+        v = C.c_uint32()
+        capi.check(self._L.okenv_get_step_count(self._h, C.byref(v)), self._h)
+        return v.value
+
+    @step_count.setter
+    def step_count(self, value):
+        capi.check(self._L.okenv_set_step_count(self._h, int(value)), self._h)
+
+    def field_device_ptr(self, field):
+        """(address, bytes) of a library-owned device array; see okenv_field_device_ptr."""
+        p, b = C.c_void_p(), C.c_uint64()
+        capi.check(self._L.okenv_field_device_ptr(self._h, int(field), C.byref(p), C.byref(b)), self._h)
+        return p.value, b.value
 
     def hits(self):
         out = np.zeros((self.N, self.R, 2), dtype=np.float32)

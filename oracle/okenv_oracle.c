@@ -284,6 +284,11 @@ typedef struct oracle_env {
     /* centre line for resets / nearest index */
     int P;
     float *cx, *cy, *chead;
+    /* inner lane boundaries (xy pairs) for resetAgent's lane randomisation; auto-reset configuration and the running
+     * step count that serves as its epoch (okenv_set_auto_reset in include/okenv.h) */
+    float *lane_l, *lane_r;
+    uint32_t reset_flags, reset_seed, reset_agent_base, step_count;
+    int auto_reset;
     /* EvolutionaryRacer: per-agent MLP weights (padded layout of okenv_math.h), scores */
     int mlp_hidden;
     float *mlp_w, *score;
@@ -322,6 +327,7 @@ ORACLE_API void oracle_env_destroy(oracle_env *e)
     free(e->disp_ctr); free(e->disp_x); free(e->disp_y); free(e->disp_to);
     free(e->hit_x); free(e->hit_y); free(e->rel_x); free(e->rel_y); free(e->dist);
     free(e->cx); free(e->cy); free(e->chead);
+    free(e->lane_l); free(e->lane_r);
     free(e->mlp_w); free(e->score);
     free(e->q_table); free(e->q_state); free(e->q_action); free(e->q_prev);
     free(e);
@@ -336,6 +342,14 @@ ORACLE_API void oracle_env_set_centerline(oracle_env *e, const float *cx, const 
 }
 
 ORACLE_API void oracle_env_set_sensor_offset(oracle_env *e, float off) { e->sensor_offset = off; }
+
+ORACLE_API void oracle_env_set_lane_bounds(oracle_env *e, const float *left_inner_xy, const float *right_inner_xy, int P)
+{
+    free(e->lane_l); free(e->lane_r);
+    e->lane_l = ALLOC(float, 2 * (size_t)P); e->lane_r = ALLOC(float, 2 * (size_t)P);
+    memcpy(e->lane_l, left_inner_xy, sizeof(float) * 2 * (size_t)P);
+    memcpy(e->lane_r, right_inner_xy, sizeof(float) * 2 * (size_t)P);
+}
 
 /* field ids shared with include/okenv.h (OKENV_F_*) */
 enum { F_POS_X = 0, F_POS_Y, F_ROT, F_SPEED, F_ACC, F_THR, F_STEER, F_MODE, F_CRASHED, F_TIMED_OUT,
@@ -398,6 +412,40 @@ ORACLE_API void oracle_env_reset_agents(oracle_env *e, const int32_t *idx, const
 {
     for (int k = 0; k < n; ++k) agent_reset(e, idx[k], x[k], y[k], rot[k]);
 }
+
+/* Environment::resetAgent (Environment/Environment.cpp:79-122) for one agent; the draws and the pose arithmetic are
+ * ok_draw_reset / ok_reset_pose of include/okenv_math.h (GetRandomValue -> Philox, static call counter -> ctr). */
+static void env_reset_agent(oracle_env *e, int i, uint32_t flags, uint32_t seed, uint32_t agent, uint32_t epoch, uint32_t ctr)
+{
+    const ok_reset_draw d = ok_draw_reset(seed, agent, epoch, ctr, (uint32_t)e->P, flags);
+    float x, y, rot;
+    ok_reset_pose(d, e->cx, e->cy, e->chead, e->lane_l, e->lane_r, &x, &y, &rot);
+    agent_reset(e, i, x, y, rot);
+}
+
+/* batch form: entry j of the call stands for the (epoch + j)-th resetAgent call of the process */
+ORACLE_API void oracle_env_reset_random(oracle_env *e, const int32_t *idx, int n, uint32_t flags, uint32_t seed,
+                                        uint32_t epoch, uint32_t agent_base)
+{
+    if (!idx) n = e->N;
+    for (int j = 0; j < n; ++j) {
+        const int a = idx ? idx[j] : j;
+        if (a < 0 || a >= e->N) continue;
+        if ((flags & OK_RESET_ONLY_DONE) && !e->crashed[a]) continue;
+        env_reset_agent(e, a, flags, seed, agent_base + (uint32_t)a, epoch, epoch + (uint32_t)j);
+    }
+}
+
+ORACLE_API void oracle_env_set_auto_reset(oracle_env *e, int enabled, uint32_t flags, uint32_t seed, uint32_t agent_base)
+{
+    e->auto_reset = enabled;
+    e->reset_flags = flags & (OK_RESET_RANDOM_POINT | OK_RESET_RANDOM_LANE | OK_RESET_RANDOM_HEADING);
+    e->reset_seed = seed;
+    e->reset_agent_base = agent_base;
+}
+
+ORACLE_API uint32_t oracle_env_get_step_count(const oracle_env *e) { return e->step_count; }
+ORACLE_API void oracle_env_set_step_count(oracle_env *e, uint32_t v) { e->step_count = v; }
 
 /* Environment/Agent.cpp:21-47 dispatch, :108-119 moveViaVelocity, :82-98 moveViaAcceleration.
  * `cos(kDeg2Rad * rot_) * speed_ * kDt` is ((cos * speed) * dt), all fp32. */
@@ -515,9 +563,25 @@ static void step_range(oracle_env *e, int a0, int a1)
     collide_range(e, a0, a1);
 }
 
+/* the caller-side idiom `if (agent->crashed_) env.resetAgent(agent, ...)` before a step
+ * (RLRacers/GuidedCostLearning/test.cpp:104-110), applied to every agent when auto-reset is on */
+static void auto_reset_pass(oracle_env *e)
+{
+    if (!e->auto_reset) return;
+    for (int i = 0; i < e->N; ++i) {
+        if (!e->crashed[i]) continue;
+        const uint32_t ag = e->reset_agent_base + (uint32_t)i;
+        env_reset_agent(e, i, e->reset_flags, e->reset_seed, ag, e->step_count, ag + e->step_count);
+    }
+}
+
 ORACLE_API void oracle_env_step(oracle_env *e, int n_steps)
 {
-    for (int s = 0; s < n_steps; ++s) step_range(e, 0, e->N);
+    for (int s = 0; s < n_steps; ++s) {
+        auto_reset_pass(e);
+        step_range(e, 0, e->N);
+        e->step_count++;
+    }
 }
 
 /* kinematics + standstill only (validated against the reference's Agent.o) */
@@ -680,7 +744,9 @@ ORACLE_API void oracle_env_rollout_policy(oracle_env *e, int n_steps)
 {
     for (int s = 0; s < n_steps; ++s) {
         for (int a = 0; a < e->N; ++a) ga_update_action(e, a);
+        auto_reset_pass(e); /* off in the reference's loop; when on, a reset agent's step runs with the zeroed action */
         step_range(e, 0, e->N);
+        e->step_count++;
     }
 }
 

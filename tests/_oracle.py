@@ -57,6 +57,13 @@ def lib():
         L.oracle_env_destroy.argtypes = [C.c_void_p]
         L.oracle_env_set_centerline.argtypes = [C.c_void_p, f32p, f32p, f32p, C.c_int]
         L.oracle_env_set_sensor_offset.argtypes = [C.c_void_p, C.c_float]
+        L.oracle_env_set_lane_bounds.argtypes = [C.c_void_p, f32p, f32p, C.c_int]
+        L.oracle_env_reset_random.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.c_uint32]
+        L.oracle_env_set_auto_reset.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.oracle_env_get_step_count.restype = C.c_uint32
+        L.oracle_env_get_step_count.argtypes = [C.c_void_p]
+        L.oracle_env_set_step_count.argtypes = [C.c_void_p, C.c_uint32]
         L.oracle_env_set_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_env_get_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_env_reset_agents.argtypes = [C.c_void_p, i32p, f32p, f32p, f32p, C.c_int]
@@ -194,6 +201,29 @@ class OracleEnv:
         lib().oracle_env_reset_agents(self.h, idx, np.ascontiguousarray(x, dtype=np.float32),
                                       np.ascontiguousarray(y, dtype=np.float32),
                                       np.ascontiguousarray(rot, dtype=np.float32), idx.size)
+
+    def set_lane_bounds(self, left_inner_xy, right_inner_xy):
+        l = np.ascontiguousarray(left_inner_xy, dtype=np.float32).reshape(-1)
+        r = np.ascontiguousarray(right_inner_xy, dtype=np.float32).reshape(-1)
+        lib().oracle_env_set_lane_bounds(self.h, l, r, l.size // 2)
+
+    def reset_random(self, idx=None, flags=1, seed=0, epoch=0, agent_base=0):
+        if idx is None:
+            lib().oracle_env_reset_random(self.h, None, 0, flags, seed, epoch, agent_base)
+        else:
+            idx = np.ascontiguousarray(idx, dtype=np.int32)
+            lib().oracle_env_reset_random(self.h, idx.ctypes.data_as(C.c_void_p), idx.size, flags, seed, epoch, agent_base)
+
+    def set_auto_reset(self, enabled, flags=1, seed=0, agent_base=0):
+        lib().oracle_env_set_auto_reset(self.h, int(bool(enabled)), flags, seed, agent_base)
+
+    @property
+    def step_count(self):
+        return lib().oracle_env_get_step_count(self.h)
+
+    @step_count.setter
+    def step_count(self, v):
+        lib().oracle_env_set_step_count(self.h, int(v))
 
     def step(self, n=1):
         lib().oracle_env_step(self.h, n)
