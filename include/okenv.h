@@ -78,7 +78,14 @@ enum okenv_field {
     OKENV_F_REL_X = 16,    /* f32 [N*R] Agent::sensor_hits_[r].x ("robot frame")    */
     OKENV_F_REL_Y = 17,    /* f32 [N*R] Agent::sensor_hits_[r].y                    */
     OKENV_F_DIST = 18,     /* f32 [N*R] Agent::sensor_hits_[r].norm()               */
-    OKENV_F_COUNT = 19
+    OKENV_F_COUNT = 19,
+    /* rollout bookkeeping; exist after okenv_tracker_create (not part of okenv_state_view / snapshots) */
+    OKENV_F_REWARD = 19,         /* f32  reward of the last okenv_tracker_update              */
+    OKENV_F_FITNESS = 20,        /* f32  CmaEsAgent::fitness_ / return of the running episode  */
+    OKENV_F_TRACK_IDX = 21,      /* i32  prev_track_idx_ (main_eigen.cpp:84)                  */
+    OKENV_F_EPISODE_STEPS = 22,  /* u32  updates since the episode began                      */
+    OKENV_F_EPISODE_RETURN = 23, /* f32  fitness at the end of the last finished episode     */
+    OKENV_F_COUNT_ALL = 24
 };
 
 /* Struct-of-pointers form of the per-agent state, for one-call upload/download by the C++ facade.
@@ -170,6 +177,22 @@ OKENV_API int okenv_set_auto_reset(okenv_t h, int32_t enabled, uint32_t flags, u
 /* Environment steps taken so far by okenv_step / okenv_rollout_policy on this handle (the auto-reset epoch). */
 OKENV_API int okenv_get_step_count(okenv_t h, uint32_t *out);
 OKENV_API int okenv_set_step_count(okenv_t h, uint32_t value);
+
+/* ---- rollout bookkeeping of the current-API population callers -------- */
+
+/* The per-step loop the living callers run after env.step() (CovarianceMatrixAdaptationEvolution/main_eigen.cpp:
+ * 143-158, RLRacers/PPO/ppo_sim.cpp:73-88), for all agents on the device. */
+#define OKENV_REWARD_STEP 0     /* +1 per step for every agent, crashed or not (ppo_sim.cpp:77-80)                   */
+#define OKENV_REWARD_PROGRESS 1 /* |curr - prev nearest centre-line index| while alive, fitness := 0 once timed out  */
+                                /* (main_eigen.cpp:147-158; the index difference is NOT wrapped at the lap seam)     */
+OKENV_API int okenv_tracker_create(okenv_t h, int32_t reward_kind);
+/* Start of an episode for every agent: prev_track_idx_ = findNearestTrackIndexBruteForce(pos_), fitness_ = 0
+ * (main_eigen.cpp:128-133, CmaEsAgent::reset :70-74).  Call after the initial-observation step. */
+OKENV_API int okenv_tracker_begin(okenv_t h);
+/* The bookkeeping after one Environment::step.  An agent that was crashed at the previous update and is not now has
+ * been re-placed (okenv_reset_random or auto-reset): its episode restarts here with reward 0 (that step was its
+ * initial observation).  An agent that crashes in this step gets OKENV_F_EPISODE_RETURN := fitness. */
+OKENV_API int okenv_tracker_update(okenv_t h);
 
 /* ---- zero-copy access for device-side callers ------------------------ */
 

@@ -23,6 +23,11 @@ FIELD_NAMES = ["pos_x", "pos_y", "rot", "speed", "acc", "thr", "steer", "mode", 
                "disp_x", "disp_y", "disp_to", "hit_x", "hit_y", "rel_x", "rel_y", "dist"]
 FIELD_DTYPE = [np.float32] * 7 + [np.uint8] * 3 + [np.uint32, np.float32, np.float32, np.uint8] + [np.float32] * 5
 PER_RAY = {F_HIT_X, F_HIT_Y, F_REL_X, F_REL_Y, F_DIST}
+# rollout bookkeeping fields (exist after okenv_tracker_create)
+F_REWARD, F_FITNESS, F_TRACK_IDX, F_EPISODE_STEPS, F_EPISODE_RETURN = range(19, 24)
+FIELD_NAMES += ["reward", "fitness", "track_idx", "episode_steps", "episode_return"]
+FIELD_DTYPE += [np.float32, np.float32, np.int32, np.uint32, np.float32]
+REWARD_STEP, REWARD_PROGRESS = 0, 1
 
 # every symbol include/okenv.h declares (tests/test_capi_symbols.py checks the library exports them all)
 SYMBOLS = [
@@ -38,7 +43,8 @@ SYMBOLS = [
     "okenv_q_create", "okenv_q_begin_episode", "okenv_rollout_q", "okenv_q_get_table", "okenv_q_set_table", "okenv_q_get_state",
     "okenv_q_table_sums", "okenv_q_assign_mean", "okenv_q_share_knowledge",
     "okenv_set_lane_bounds", "okenv_reset_random", "okenv_set_auto_reset", "okenv_get_step_count",
-    "okenv_set_step_count", "okenv_field_device_ptr",
+    "okenv_set_step_count", "okenv_field_device_ptr", "okenv_tracker_create", "okenv_tracker_begin",
+    "okenv_tracker_update",
 ]
 
 
@@ -138,6 +144,9 @@ def load(build_if_missing=True):
     L.okenv_set_auto_reset.argtypes = [vp, i32, u32, u32, u32]
     L.okenv_get_step_count.argtypes = [vp, C.POINTER(u32)]
     L.okenv_set_step_count.argtypes = [vp, u32]
+    L.okenv_tracker_create.argtypes = [vp, i32]
+    L.okenv_tracker_begin.argtypes = [vp]
+    L.okenv_tracker_update.argtypes = [vp]
     L.okenv_field_device_ptr.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_uint64)]
     _lib = L
     return L

@@ -1,0 +1,139 @@
+"""CMA-ES population racing on the device environment.
+
+Mirror of the reference's CovarianceMatrixAdaptationEvolution app for N candidates at once:
+  * `CmaEsSolver`      -- CmaEsSolverEigen.cpp:26-132 (host, float64; the rank-mu/rank-one update of arXiv:1604.00772)
+  * `BatchedController`-- Controller.cpp:3-23, one parameter vector per candidate, evaluated with batched matmuls
+  * `CmaEsRacers`      -- the generation loop of main_eigen.cpp:113-171: sample, resetAgent, one observation step, then
+                          {updateAction; env.step(); fitness += |index progress|} until every candidate has crashed.
+The environment step and the fitness bookkeeping are libokenv.so kernels (okenv_step, okenv_tracker_update); the
+policy forward is plain PyTorch on the same stream.  The reference seeds std::mt19937 from std::random_device
+(CmaEsSolverEigen.h:49), so its sample streams are not reproducible; here a seeded numpy Generator draws z.
+"""
+import numpy as np
+import torch
+
+from . import _capi as capi
+from .torch_env import VectorEnvironment
+
+
+class CmaEsSolver:
+    def __init__(self, num_params, population_size, seed=0, sigma=0.5):
+        n, lam = int(num_params), int(population_size)
+        self.num_params, self.population_size, self.num_parents = n, lam, lam // 2
+        self.sigma = float(sigma)
+        self.mean = np.zeros(n)
+        self.C = np.eye(n)
+        self.p_sigma = np.zeros(n)
+        self.p_c = np.zeros(n)
+        mu = self.num_parents
+        w = np.log(mu + 0.5) - np.log(np.arange(1, mu + 1))
+        self.weights = w / w.sum()
+        self.mu_eff = 1.0 / np.sum(self.weights ** 2)
+        self.c_sigma = (self.mu_eff + 2.0) / (n + self.mu_eff + 5.0)
+        self.d_sigma = 1.0 + 2.0 * max(0.0, np.sqrt((self.mu_eff - 1.0) / (n + 1.0)) - 1.0) + self.c_sigma
+        self.c_c = (4.0 + self.mu_eff / n) / (n + 4.0 + 2.0 * self.mu_eff / n)
+        self.c_1 = 2.0 / ((n + 1.3) ** 2 + self.mu_eff)
+        self.c_mu = min(1.0 - self.c_1, 2.0 * (self.mu_eff - 2.0 + 1.0 / self.mu_eff) / ((n + 2.0) ** 2 + self.mu_eff))
+        self.chi_n = np.sqrt(n) * (1.0 - 1.0 / (4.0 * n) + 1.0 / (21.0 * n * n))
+        self.B = np.eye(n)
+        self.D = np.ones(n)
+        self.rng = np.random.default_rng(seed)
+
+    def sample(self):
+        """Candidates x_i = mean + sigma * B (D * z_i), z_i ~ N(0, I); returns float32 [population, num_params]."""
+        evals, self.B = np.linalg.eigh(self.C)
+        self.D = np.sqrt(evals)
+        z = self.rng.standard_normal((self.population_size, self.num_params))
+        y = (z * self.D) @ self.B.T
+        return (self.mean + self.sigma * y).astype(np.float32)
+
+    def tell(self, solutions, fitness):
+        """Higher fitness is better (the reference sorts descending, CmaEsSolverEigen.cpp:86-90)."""
+        x = np.asarray(solutions, dtype=np.float64)
+        order = np.argsort(-np.asarray(fitness, dtype=np.float64), kind="stable")[: self.num_parents]
+        old_mean = self.mean
+        parents = x[order]
+        self.mean = self.weights @ parents
+        y_w = (self.mean - old_mean) / self.sigma
+        inv_sqrt_c = (self.B / self.D) @ self.B.T
+        self.p_sigma = (1.0 - self.c_sigma) * self.p_sigma + np.sqrt(self.c_sigma * (2.0 - self.c_sigma) * self.mu_eff) * (inv_sqrt_c @ y_w)
+        self.p_c = (1.0 - self.c_c) * self.p_c + np.sqrt(self.c_c * (2.0 - self.c_c) * self.mu_eff) * y_w
+        y = (parents - old_mean) / self.sigma
+        rank_mu = (y * self.weights[:, None]).T @ y
+        self.C = (1.0 - self.c_1 - self.c_mu) * self.C + self.c_1 * np.outer(self.p_c, self.p_c) + self.c_mu * rank_mu
+        self.sigma *= np.exp((self.c_sigma / self.d_sigma) * (np.linalg.norm(self.p_sigma) / self.chi_n - 1.0))
+
+    def get_best_solution(self):
+        return self.mean.astype(np.float32)
+
+
+class BatchedController:
+    """tanh(fc3(tanh(fc2(tanh(fc1(x)))))) with fc1: in->h, fc2: h->h/2, fc3: h/2->out, one weight set per candidate.
+    The flat parameter order is torch's `parameters()` order of the reference module: fc1.weight [h, in] row-major,
+    fc1.bias, fc2.weight, fc2.bias, fc3.weight, fc3.bias (Controller.cpp:36-53)."""
+
+    def __init__(self, input_size, hidden_size, output_size, device):
+        self.sizes = [(hidden_size, input_size), (hidden_size // 2, hidden_size), (output_size, hidden_size // 2)]
+        self.device = device
+        self.layers = None
+
+    def count_params(self):
+        return sum(o * i + o for o, i in self.sizes)
+
+    def set_params(self, flat):
+        flat = torch.as_tensor(flat, dtype=torch.float32, device=self.device)
+        assert flat.dim() == 2 and flat.shape[1] == self.count_params()
+        self.layers, off = [], 0
+        for o, i in self.sizes:
+            w = flat[:, off:off + o * i].reshape(-1, o, i)
+            off += o * i
+            b = flat[:, off:off + o].unsqueeze(2)
+            off += o
+            self.layers.append((w, b))
+
+    def forward(self, x):
+        x = x.unsqueeze(2)
+        for w, b in self.layers:
+            x = torch.tanh(torch.baddbmm(b, w, x))
+        return x.squeeze(2)
+
+
+class CmaEsRacers:
+    RAYS = (-70.0, -30.0, 0.0, 30.0, 70.0)  # CmaEsAgent's fan (main_eigen.cpp:26-31)
+    HIDDEN, OUTPUTS = 16, 2                  # main_eigen.cpp:18-19
+
+    def __init__(self, track, population_size=20, device=0, seed=0, reset_randomly=False, max_steps=None):
+        self.venv = VectorEnvironment(track, population_size, ray_angles_deg=np.array(self.RAYS, dtype=np.float32),
+                                      device=device, movement_mode=capi.MODE_VELOCITY, auto_reset=False,
+                                      pick_random_point=reset_randomly, seed=seed, reward="progress")
+        self.controller = BatchedController(len(self.RAYS), self.HIDDEN, self.OUTPUTS, self.venv.device)
+        self.solver = CmaEsSolver(self.controller.count_params(), population_size, seed=seed)
+        self.max_steps = max_steps
+        self.generation = 0
+
+    def update_action(self):
+        """CmaEsAgent::updateAction (main_eigen.cpp:58-68): full throttle, steering = 5 * first output."""
+        out = self.controller.forward(self.venv.observation())
+        self.venv.set_action(100.0, out[:, 0] * 5.0)
+
+    def run_generation(self, check_every=16):
+        """One pass of the while(true) body, main_eigen.cpp:113-182; returns (best fitness, steps taken)."""
+        venv = self.venv
+        population = self.solver.sample()
+        self.controller.set_params(population)
+        # resetAgent for every candidate, the initial-observation step, prev_track_idx_ (main_eigen.cpp:120-133)
+        venv.reset(epoch=self.generation)
+        steps = 0
+        while True:
+            self.update_action()
+            venv.step()
+            steps += 1
+            # crashed agents neither move nor score, so looking at the flags every few steps changes nothing
+            if steps % check_every == 0 and venv.env.alive_count() == 0:
+                break
+            if self.max_steps is not None and steps >= self.max_steps:
+                break
+        fitness = venv.fitness.cpu().numpy().astype(np.float64)
+        self.solver.tell(population, fitness)
+        self.generation += 1
+        return float(fitness.max()), steps

@@ -57,6 +57,8 @@ struct okenv
     float      *d_lane_l{nullptr}, *d_lane_r{nullptr}; // left_bound_inner_ / right_bound_inner_, xy pairs
     int         lane_points{0}, lane_capacity{0};
     uint32_t    reset_flags{0}, reset_seed{0}, reset_agent_base{0}; // okenv_set_auto_reset
+    OkTracker   tracker{};
+    int         tracker_kind{-1};
     uint32_t    step_count{0};                                      // Environment steps taken by okenv_step / okenv_rollout_policy
     OkDeviceState st{};
     std::vector<void *> allocations;
@@ -155,6 +157,11 @@ FieldDesc fieldOf(okenv *h, const int f)
     case OKENV_F_REL_X: return {s.rel_x, 4 * NR};
     case OKENV_F_REL_Y: return {s.rel_y, 4 * NR};
     case OKENV_F_DIST: return {s.dist, 4 * NR};
+    case OKENV_F_REWARD: return {h->tracker.reward, h->tracker.reward ? 4 * N : 0};
+    case OKENV_F_FITNESS: return {h->tracker.fitness, h->tracker.fitness ? 4 * N : 0};
+    case OKENV_F_TRACK_IDX: return {h->tracker.prev_idx, h->tracker.prev_idx ? 4 * N : 0};
+    case OKENV_F_EPISODE_STEPS: return {h->tracker.ep_steps, h->tracker.ep_steps ? 4 * N : 0};
+    case OKENV_F_EPISODE_RETURN: return {h->tracker.ep_return, h->tracker.ep_return ? 4 * N : 0};
     default: return {nullptr, 0};
     }
 }
@@ -544,7 +551,7 @@ extern "C"
             return fail(h, OKENV_ERR_INVALID, "okenv_set_field: NULL argument");
         const FieldDesc d = fieldOf(h, field);
         if (!d.ptr)
-            return fail(h, OKENV_ERR_INVALID, "okenv_set_field: unknown field");
+            return fail(h, OKENV_ERR_INVALID, "okenv_set_field: unknown field (tracker fields exist after okenv_tracker_create)");
         int rc = copyAny(h, d.ptr, src, d.bytes);
         if (rc != OKENV_OK)
             return rc;
@@ -558,7 +565,7 @@ extern "C"
             return fail(h, OKENV_ERR_INVALID, "okenv_get_field: NULL argument");
         const FieldDesc d = fieldOf(h, field);
         if (!d.ptr)
-            return fail(h, OKENV_ERR_INVALID, "okenv_get_field: unknown field");
+            return fail(h, OKENV_ERR_INVALID, "okenv_get_field: unknown field (tracker fields exist after okenv_tracker_create)");
         int rc = copyAny(h, dst, d.ptr, d.bytes);
         if (rc != OKENV_OK)
             return rc;
@@ -742,7 +749,7 @@ extern "C"
             return fail(h, OKENV_ERR_INVALID, "okenv_field_device_ptr: NULL argument");
         const FieldDesc d = fieldOf(h, field);
         if (!d.ptr)
-            return fail(h, OKENV_ERR_INVALID, "okenv_field_device_ptr: unknown field");
+            return fail(h, OKENV_ERR_INVALID, "okenv_field_device_ptr: unknown field (tracker fields exist after okenv_tracker_create)");
         *ptr = d.ptr;
         if (bytes)
             *bytes = d.bytes;
@@ -875,6 +882,51 @@ extern "C"
         OK_HIP(h, hipFreeAsync(dout, h->stream));
         OK_HIP(h, hipStreamSynchronize(h->stream));
         return OKENV_OK;
+    }
+
+    // ---- rollout bookkeeping ---------------------------------------------------------------------------------------
+
+    int okenv_tracker_create(okenv_t h, int32_t reward_kind)
+    {
+        if (!h || (reward_kind != OKENV_REWARD_STEP && reward_kind != OKENV_REWARD_PROGRESS))
+            return fail(h, OKENV_ERR_INVALID, "okenv_tracker_create: unknown reward kind");
+        if (h->P <= 0)
+            return fail(h, OKENV_ERR_STATE, "okenv_tracker_create: call okenv_set_centerline first");
+        OK_HIP(h, hipSetDevice(h->device));
+        if (!h->tracker.fitness)
+        {
+            const size_t N = static_cast<size_t>(h->N);
+            int          rc;
+            if ((rc = devAlloc(h, &h->tracker.prev_idx, N)) || (rc = devAlloc(h, &h->tracker.fitness, N)) ||
+                (rc = devAlloc(h, &h->tracker.reward, N)) || (rc = devAlloc(h, &h->tracker.ep_steps, N)) ||
+                (rc = devAlloc(h, &h->tracker.ep_return, N)) || (rc = devAlloc(h, &h->tracker.prev_crashed, N)))
+                return rc;
+        }
+        h->tracker_kind = reward_kind;
+        return OKENV_OK;
+    }
+
+    static int launchTracker(okenv_t h, const int begin, const char *who)
+    {
+        if (!h)
+            return OKENV_ERR_INVALID;
+        if (h->tracker_kind < 0)
+            return fail(h, OKENV_ERR_STATE, std::string(who) + ": call okenv_tracker_create first");
+        OK_HIP(h, hipSetDevice(h->device));
+        hipLaunchKernelGGL(okTrackerKernel, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->st, h->d_cx, h->d_cy, h->P, h->tracker,
+                           h->N, h->tracker_kind, begin);
+        OK_HIP(h, hipGetLastError());
+        return OKENV_OK;
+    }
+
+    int okenv_tracker_begin(okenv_t h)
+    {
+        return launchTracker(h, 1, "okenv_tracker_begin");
+    }
+
+    int okenv_tracker_update(okenv_t h)
+    {
+        return launchTracker(h, 0, "okenv_tracker_update");
     }
 
     // ---- EvolutionaryRacer ---------------------------------------------------------------------------------------

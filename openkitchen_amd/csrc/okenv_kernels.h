@@ -848,14 +848,12 @@ __global__ void okInitBenchKernel(OkDeviceState st, const float *cx, const float
 }
 
 // RaceTrack::findNearestTrackIndexBruteForce (RaceTrack.cpp:16-31): one thread per query, centre line
-// staged in LDS in chunks; strict '<' so the lowest index wins ties, like the sequential scan.
-__global__ void okNearestIdxKernel(const float *cx, const float *cy, int P, const float *qx, const float *qy, int n, int32_t *out)
+// staged in LDS in chunks; strict '<' so the lowest index wins ties, like the sequential scan.  Every thread of the
+// workgroup must call it (barriers inside); `sx`/`sy` are two 1024-float LDS arrays.
+__device__ __forceinline__ int okNearestIdx(const float *cx, const float *cy, const int P, const float px, const float py, float *sx, float *sy)
 {
-    __shared__ float sx[1024], sy[1024];
-    const int        i  = blockIdx.x * blockDim.x + threadIdx.x;
-    const float      px = (i < n) ? qx[i] : 0.F, py = (i < n) ? qy[i] : 0.F;
-    float            bestv = 3.402823466e+38F; // FLT_MAX, as in the reference
-    int              arg   = 0;
+    float bestv = 3.402823466e+38F; // FLT_MAX, as in the reference
+    int   arg   = 0;
     for (int base = 0; base < P; base += 1024)
     {
         const int m = (P - base < 1024) ? (P - base) : 1024;
@@ -877,8 +875,88 @@ __global__ void okNearestIdxKernel(const float *cx, const float *cy, int P, cons
             }
         }
     }
+    return arg;
+}
+
+__global__ void okNearestIdxKernel(const float *cx, const float *cy, int P, const float *qx, const float *qy, int n, int32_t *out)
+{
+    __shared__ float sx[1024], sy[1024];
+    const int        i  = blockIdx.x * blockDim.x + threadIdx.x;
+    const float      px = (i < n) ? qx[i] : 0.F, py = (i < n) ? qy[i] : 0.F;
+    const int        arg = okNearestIdx(cx, cy, P, px, py, sx, sy);
     if (i < n)
         out[i] = arg;
+}
+
+// ---- rollout bookkeeping ------------------------------------------------------------
+
+struct OkTracker
+{
+    int32_t  *prev_idx;     // prev_track_idx_
+    float    *fitness;      // fitness_ / running return
+    float    *reward;       // of the last update
+    uint32_t *ep_steps;
+    float    *ep_return;    // fitness when the last episode ended
+    uint8_t  *prev_crashed; // crashed_ as of the previous update
+};
+
+enum OkRewardKind : int
+{
+    kRewardStep     = 0, // ppo_sim.cpp:77-80
+    kRewardProgress = 1, // main_eigen.cpp:147-158
+};
+
+// The callers' loop body after env.step(), one thread per agent (begin != 0: the episode start of main_eigen.cpp:128-133).
+__global__ void okTrackerKernel(OkDeviceState st, const float *cx, const float *cy, int P, OkTracker tr, int N, int kind, int begin)
+{
+    __shared__ float sx[1024], sy[1024];
+    const int        i   = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool       ok  = i < N;
+    const int        idx = okNearestIdx(cx, cy, P, ok ? st.pos_x[i] : 0.F, ok ? st.pos_y[i] : 0.F, sx, sy);
+    if (!ok)
+        return;
+    const bool crashed = st.crashed[i] != 0;
+    if (begin)
+    {
+        tr.prev_idx[i]     = idx;
+        tr.fitness[i]      = 0.F;
+        tr.reward[i]       = 0.F;
+        tr.ep_steps[i]     = 0U;
+        tr.prev_crashed[i] = crashed ? 1 : 0;
+        return;
+    }
+    const bool was_crashed = tr.prev_crashed[i] != 0;
+    float      fitness     = tr.fitness[i];
+    float      reward      = 0.F;
+    if (was_crashed && !crashed)
+    { // re-placed since the last update: this step was the new episode's initial observation
+        fitness        = 0.F;
+        tr.ep_steps[i] = 0U;
+        tr.prev_idx[i] = idx;
+    }
+    else if (kind == kRewardStep)
+    {
+        reward = 1.F;
+        fitness += 1.F;
+        tr.ep_steps[i] += 1U;
+    }
+    else if (!crashed)
+    {
+        const int progress = idx - tr.prev_idx[i];
+        tr.prev_idx[i]     = idx;
+        reward             = static_cast<float>(progress < 0 ? -progress : progress);
+        fitness += reward;
+        tr.ep_steps[i] += 1U;
+    }
+    else if (st.timed_out[i] != 0)
+    {
+        fitness = 0.F;
+    }
+    tr.fitness[i] = fitness;
+    tr.reward[i]  = reward;
+    if (crashed && !was_crashed)
+        tr.ep_return[i] = fitness;
+    tr.prev_crashed[i] = crashed ? 1 : 0;
 }
 
 // ---- EvolutionaryRacer generation kernels ---------------------------------------

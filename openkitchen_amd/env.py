@@ -178,6 +178,19 @@ class BatchedEnvironment:
     def step_count(self, value):
         capi.check(self._L.okenv_set_step_count(self._h, int(value)), self._h)
 
+    # ---- rollout bookkeeping of the CMA-ES / PPO style callers (include/okenv.h) -----------------------------
+    def tracker_create(self, reward_kind):
+        capi.check(self._L.okenv_tracker_create(self._h, int(reward_kind)), self._h)
+
+    def tracker_begin(self):
+        capi.check(self._L.okenv_tracker_begin(self._h), self._h)
+
+    def tracker_update(self):
+        capi.check(self._L.okenv_tracker_update(self._h), self._h)
+
+    def tracker_snapshot(self):
+        return {capi.FIELD_NAMES[f]: self.get(f) for f in range(capi.F_REWARD, capi.F_EPISODE_RETURN + 1)}
+
     def field_device_ptr(self, field):
         """(address, bytes) of a library-owned device array; see okenv_field_device_ptr."""
         p, b = C.c_void_p(), C.c_uint64()

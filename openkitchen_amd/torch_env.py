@@ -32,18 +32,22 @@ class VectorEnvironment:
     Field tensors (views, no copies): `distances` [N, R] = sensor_hits_[r].norm(), `rel_x/rel_y` [N, R] =
     sensor_hits_, `hit_x/hit_y`, `pos_x, pos_y, rot, speed, acceleration, throttle, steering` [N] f32,
     `crashed, timed_out, mode` [N] u8.  `done` is `crashed` viewed as bool (Agent::crashed_ covers wall hits and
-    standstill timeouts).
+    standstill timeouts).  With `reward="step"` (+1 per step, RLRacers/PPO/ppo_sim.cpp:77-80)
+    or `reward="progress"` (centre-line index progress, CovarianceMatrixAdaptationEvolution/main_eigen.cpp:147-158)
+    also `reward, fitness, episode_return` [N] f32, `episode_steps` [N] u32, `track_idx` [N] i32, updated by `step`.
     """
 
     FIELDS = {"pos_x": capi.F_POS_X, "pos_y": capi.F_POS_Y, "rot": capi.F_ROT, "speed": capi.F_SPEED,
               "acceleration": capi.F_ACC, "throttle": capi.F_THROTTLE, "steering": capi.F_STEER, "mode": capi.F_MODE,
               "crashed": capi.F_CRASHED, "timed_out": capi.F_TIMED_OUT, "hit_x": capi.F_HIT_X, "hit_y": capi.F_HIT_Y,
               "rel_x": capi.F_REL_X, "rel_y": capi.F_REL_Y, "distances": capi.F_DIST}
+    TRACKER_FIELDS = {"reward": capi.F_REWARD, "fitness": capi.F_FITNESS, "track_idx": capi.F_TRACK_IDX,
+                      "episode_steps": capi.F_EPISODE_STEPS, "episode_return": capi.F_EPISODE_RETURN}
     SENSOR_RANGE = 200.0  # Agent::kSensorRange (Environment/Agent.h:10)
 
     def __init__(self, race_track_path, num_envs, num_rays=15, ray_angles_deg=None, device=0,
                  movement_mode=capi.MODE_VELOCITY, auto_reset=True, pick_random_point=True, randomize_lane=False,
-                 randomize_heading=False, seed=0, agent_base=0, draw_rays=False, hidden_window=True):
+                 randomize_heading=False, seed=0, agent_base=0, reward=None, draw_rays=False, hidden_window=True):
         # draw_rays / hidden_window: accepted for signature compatibility; there is no window (rendering is out of scope)
         del draw_rays, hidden_window
         if not torch.cuda.is_available():
@@ -63,14 +67,21 @@ class VectorEnvironment:
                 setattr(self, name, self._view(f))
             self.done = self.crashed.view(torch.bool)
             self.mode.fill_(int(movement_mode))
-        self.env.set_auto_reset(bool(auto_reset), self.reset_flags, self.seed, self.agent_base)
+            # rollout bookkeeping on the device: reward / fitness / episode length (okenv_tracker_*)
+            self.reward_kind = {None: None, "step": capi.REWARD_STEP, "progress": capi.REWARD_PROGRESS}[reward]
+            if self.reward_kind is not None:
+                self.env.tracker_create(self.reward_kind)
+                for name, f in self.TRACKER_FIELDS.items():
+                    setattr(self, name, self._view(f))
+        self.auto_reset = bool(auto_reset)
+        self.env.set_auto_reset(self.auto_reset, self.reset_flags, self.seed, self.agent_base)
         # Pybind/bindings.cpp:27-33: the agent starts on a (random) centre-line point with the track heading
         self.env.reset_random(None, capi.RESET_RANDOM_POINT if pick_random_point else 0, self.seed, 0xFFFFFFFF,
                               self.agent_base)
 
     def _view(self, field):
         address, nbytes = self.env.field_device_ptr(field)
-        dtype = torch.from_numpy(capi.FIELD_DTYPE[field]().reshape(1)).dtype
+        dtype = torch.from_numpy(capi.FIELD_DTYPE[field](0).reshape(1)).dtype
         shape = (self.num_envs, self.num_rays) if field in capi.PER_RAY else (self.num_envs,)
         t = torch.as_tensor(_DeviceArray(address, shape, dtype, self.env), device=self.device)
         assert t.data_ptr() == address and t.numel() * t.element_size() == nbytes
@@ -98,6 +109,8 @@ class VectorEnvironment:
         if actions is not None:
             self.set_action(actions[:, 0], actions[:, 1])
         self.env.step(n_steps)
+        if self.reward_kind is not None:
+            self.env.tracker_update()
         return self.distances, self.done
 
     # ---- conveniences for learners ----------------------------------------------------------------------------------
@@ -118,6 +131,11 @@ class VectorEnvironment:
             if idx.numel():
                 self.env.reset_random(idx, self.reset_flags, self.seed, epoch, self.agent_base)
         self.env.step(1)
+        if self.reward_kind is not None:
+            if mask is None:
+                self.env.tracker_begin()
+            else:
+                self.env.tracker_update()  # re-placed agents restart their episode, the others take a normal step
         return self.distances, self.done
 
     def nearest_track_idx(self):

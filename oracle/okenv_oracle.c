@@ -289,6 +289,12 @@ typedef struct oracle_env {
     float *lane_l, *lane_r;
     uint32_t reset_flags, reset_seed, reset_agent_base, step_count;
     int auto_reset;
+    /* rollout bookkeeping of the CMA-ES / PPO callers (okenv_tracker_* in include/okenv.h) */
+    int tracker_kind;
+    int32_t *tr_prev_idx;
+    float *tr_fitness, *tr_reward, *tr_ep_return;
+    uint32_t *tr_ep_steps;
+    uint8_t *tr_prev_crashed;
     /* EvolutionaryRacer: per-agent MLP weights (padded layout of okenv_math.h), scores */
     int mlp_hidden;
     float *mlp_w, *score;
@@ -328,6 +334,8 @@ ORACLE_API void oracle_env_destroy(oracle_env *e)
     free(e->hit_x); free(e->hit_y); free(e->rel_x); free(e->rel_y); free(e->dist);
     free(e->cx); free(e->cy); free(e->chead);
     free(e->lane_l); free(e->lane_r);
+    free(e->tr_prev_idx); free(e->tr_fitness); free(e->tr_reward); free(e->tr_ep_return); free(e->tr_ep_steps);
+    free(e->tr_prev_crashed);
     free(e->mlp_w); free(e->score);
     free(e->q_table); free(e->q_state); free(e->q_action); free(e->q_prev);
     free(e);
@@ -353,7 +361,8 @@ ORACLE_API void oracle_env_set_lane_bounds(oracle_env *e, const float *left_inne
 
 /* field ids shared with include/okenv.h (OKENV_F_*) */
 enum { F_POS_X = 0, F_POS_Y, F_ROT, F_SPEED, F_ACC, F_THR, F_STEER, F_MODE, F_CRASHED, F_TIMED_OUT,
-       F_DISP_CTR, F_DISP_X, F_DISP_Y, F_DISP_TO, F_HIT_X, F_HIT_Y, F_REL_X, F_REL_Y, F_DIST, F_COUNT };
+       F_DISP_CTR, F_DISP_X, F_DISP_Y, F_DISP_TO, F_HIT_X, F_HIT_Y, F_REL_X, F_REL_Y, F_DIST, F_COUNT,
+       F_REWARD = F_COUNT, F_FITNESS, F_TRACK_IDX, F_EPISODE_STEPS, F_EPISODE_RETURN };
 
 static void *field_ptr(oracle_env *e, int f, size_t *bytes)
 {
@@ -378,6 +387,11 @@ static void *field_ptr(oracle_env *e, int f, size_t *bytes)
     case F_REL_X: *bytes = 4 * NR; return e->rel_x;
     case F_REL_Y: *bytes = 4 * NR; return e->rel_y;
     case F_DIST: *bytes = 4 * NR; return e->dist;
+    case F_REWARD: *bytes = 4 * N; return e->tr_reward;
+    case F_FITNESS: *bytes = 4 * N; return e->tr_fitness;
+    case F_TRACK_IDX: *bytes = 4 * N; return e->tr_prev_idx;
+    case F_EPISODE_STEPS: *bytes = 4 * N; return e->tr_ep_steps;
+    case F_EPISODE_RETURN: *bytes = 4 * N; return e->tr_ep_return;
     default: *bytes = 0; return NULL;
     }
 }
@@ -935,4 +949,60 @@ ORACLE_API void oracle_q_get_table(const oracle_env *e, float *out)
 ORACLE_API void oracle_q_get_state(const oracle_env *e, int32_t *state, int32_t *action, int32_t *prev)
 {
     memcpy(state, e->q_state, 4 * (size_t)e->N); memcpy(action, e->q_action, 4 * (size_t)e->N); memcpy(prev, e->q_prev, 4 * (size_t)e->N);
+}
+
+/* ============================================================================================ */
+/* Rollout bookkeeping of the living population callers            */
+/* ============================================================================================ */
+
+/* reward kinds, as in include/okenv.h: 0 = +1 per step (RLRacers/PPO/ppo_sim.cpp:77-80),
+ * 1 = index progress (CovarianceMatrixAdaptationEvolution/main_eigen.cpp:147-158) */
+ORACLE_API void oracle_tracker_create(oracle_env *e, int kind)
+{
+    if (!e->tr_fitness) {
+        e->tr_prev_idx = ALLOC(int32_t, e->N); e->tr_fitness = ALLOC(float, e->N); e->tr_reward = ALLOC(float, e->N);
+        e->tr_ep_return = ALLOC(float, e->N); e->tr_ep_steps = ALLOC(uint32_t, e->N);
+        e->tr_prev_crashed = ALLOC(uint8_t, e->N);
+    }
+    e->tracker_kind = kind;
+}
+
+/* main_eigen.cpp:128-133 (prev_track_idx_ after the initial-observation step) and :70-74 (fitness_ = 0 in reset) */
+ORACLE_API void oracle_tracker_begin(oracle_env *e)
+{
+    for (int a = 0; a < e->N; ++a) {
+        e->tr_prev_idx[a] = nearest_index(e, e->pos_x[a], e->pos_y[a]);
+        e->tr_fitness[a] = 0.0f; e->tr_reward[a] = 0.0f; e->tr_ep_steps[a] = 0;
+        e->tr_prev_crashed[a] = e->crashed[a];
+    }
+}
+
+/* the loop body after env.step(): main_eigen.cpp:143-158 / ppo_sim.cpp:73-88; an agent that was crashed at the last
+ * update and is not now was re-placed in between, so its episode starts over (reward 0 for its observation step) */
+ORACLE_API void oracle_tracker_update(oracle_env *e)
+{
+    for (int a = 0; a < e->N; ++a) {
+        const int crashed = e->crashed[a], was = e->tr_prev_crashed[a];
+        float reward = 0.0f;
+        if (was && !crashed) {
+            e->tr_fitness[a] = 0.0f; e->tr_ep_steps[a] = 0;
+            e->tr_prev_idx[a] = nearest_index(e, e->pos_x[a], e->pos_y[a]);
+        } else if (e->tracker_kind == 0) {
+            reward = 1.0f;
+            e->tr_fitness[a] += 1.0f;
+            e->tr_ep_steps[a]++;
+        } else if (!crashed) {
+            const int32_t curr = nearest_index(e, e->pos_x[a], e->pos_y[a]);
+            const int32_t progress = curr - e->tr_prev_idx[a];
+            e->tr_prev_idx[a] = curr;
+            reward = (float)abs(progress);
+            e->tr_fitness[a] += reward;
+            e->tr_ep_steps[a]++;
+        } else if (e->timed_out[a]) {
+            e->tr_fitness[a] = 0.0f;
+        }
+        e->tr_reward[a] = reward;
+        if (crashed && !was) e->tr_ep_return[a] = e->tr_fitness[a];
+        e->tr_prev_crashed[a] = (uint8_t)crashed;
+    }
 }

@@ -26,6 +26,12 @@ FIELD_DTYPE = {
     F_HIT_Y: np.float32, F_REL_X: np.float32, F_REL_Y: np.float32, F_DIST: np.float32,
 }
 PER_RAY = {F_HIT_X, F_HIT_Y, F_REL_X, F_REL_Y, F_DIST}
+# rollout bookkeeping fields (exist after tracker_create)
+F_REWARD, F_FITNESS, F_TRACK_IDX, F_EPISODE_STEPS, F_EPISODE_RETURN = range(19, 24)
+FIELD_DTYPE.update({F_REWARD: np.float32, F_FITNESS: np.float32, F_TRACK_IDX: np.int32, F_EPISODE_STEPS: np.uint32,
+                    F_EPISODE_RETURN: np.float32})
+TRACKER_FIELDS = {"reward": F_REWARD, "fitness": F_FITNESS, "track_idx": F_TRACK_IDX, "episode_steps": F_EPISODE_STEPS,
+                  "episode_return": F_EPISODE_RETURN}
 FIELD_NAMES = ["pos_x", "pos_y", "rot", "speed", "acc", "thr", "steer", "mode", "crashed", "timed_out", "disp_ctr",
                "disp_x", "disp_y", "disp_to", "hit_x", "hit_y", "rel_x", "rel_y", "dist"]
 
@@ -64,6 +70,9 @@ def lib():
         L.oracle_env_get_step_count.restype = C.c_uint32
         L.oracle_env_get_step_count.argtypes = [C.c_void_p]
         L.oracle_env_set_step_count.argtypes = [C.c_void_p, C.c_uint32]
+        L.oracle_tracker_create.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_tracker_begin.argtypes = [C.c_void_p]
+        L.oracle_tracker_update.argtypes = [C.c_void_p]
         L.oracle_env_set_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_env_get_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_env_reset_agents.argtypes = [C.c_void_p, i32p, f32p, f32p, f32p, C.c_int]
@@ -224,6 +233,18 @@ class OracleEnv:
     @step_count.setter
     def step_count(self, v):
         lib().oracle_env_set_step_count(self.h, int(v))
+
+    def tracker_create(self, kind):
+        lib().oracle_tracker_create(self.h, int(kind))
+
+    def tracker_begin(self):
+        lib().oracle_tracker_begin(self.h)
+
+    def tracker_update(self):
+        lib().oracle_tracker_update(self.h)
+
+    def tracker_snapshot(self):
+        return {k: self.get(f) for k, f in TRACKER_FIELDS.items()}
 
     def step(self, n=1):
         lib().oracle_env_step(self.h, n)
