@@ -83,6 +83,68 @@ def cpu_baseline(track_name, R, seed, log):
     return out
 
 
+def bench_callers(args, torch, local_rank, log):
+    """Secondary figures for the callers of SURVEY.md section 8f on the tensor binding: one kernel launch per Environment
+    step with a PyTorch policy in between (PPO-shaped loop) and one CMA-ES generation.  Rank 0, N=1 only."""
+    from openkitchen_amd.cmaes import CmaEsRacers
+    from openkitchen_amd.rollout import PPO_ACTIONS
+    from openkitchen_amd.torch_env import VectorEnvironment
+    out = {}
+    N, steps = args.agents, 300
+    fan = np.array([-70, -30, 0, 30, 70], dtype=np.float32)
+    venv = VectorEnvironment(args.track, N, ray_angles_deg=fan, device=local_rank, auto_reset=True, randomize_lane=True,
+                             randomize_heading=True, seed=args.seed, reward="step")
+    torch.manual_seed(args.seed)
+    actor = torch.nn.Sequential(torch.nn.Linear(5, 128), torch.nn.ReLU(), torch.nn.Linear(128, 3), torch.nn.Softmax(dim=1)).cuda()
+    table = torch.tensor(PPO_ACTIONS, dtype=torch.float32, device=venv.device)
+    venv.reset()
+
+    def loop(n):
+        with torch.no_grad():
+            for _ in range(n):
+                probs = torch.clamp(actor(venv.observation()), 1e-8, 1.0 - 1e-8)
+                venv.step(table[torch.multinomial(probs, 1).squeeze(1)])
+
+    loop(20)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["vector_env_torch_policy"] = {
+        "value": N * steps / dt, "unit": "agent-steps/s", "us_per_step": dt / steps * 1e6,
+        "workload": "%d agents x 5 rays, %s, PPO actor 5-128-3 in PyTorch + multinomial between steps, device auto-reset "
+                    "(lane + heading), +1 reward bookkeeping; one okenv_step launch per step" % (N, args.track),
+        "episodes_finished": int((venv.episode_return > 0).sum())}
+    # the same iteration captured once into a HIP graph and replayed (VectorEnvironment.capture)
+    graph = venv.capture(lambda: loop(1))
+    for _ in range(20):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["vector_env_torch_policy_graph"] = {"value": N * steps / dt, "unit": "agent-steps/s", "us_per_step": dt / steps * 1e6,
+                                            "workload": "same iteration, captured into one HIP graph and replayed"}
+    venv.close()
+    racers = CmaEsRacers(args.track, N, device=local_rank, seed=args.seed, max_steps=400)
+    racers.run_generation()  # warm-up (eigh, allocator)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    best, gsteps = racers.run_generation()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["cmaes_generation"] = {
+        "value": N * gsteps / dt, "unit": "agent-steps/s", "generation_ms": dt * 1e3, "steps": gsteps, "best_fitness": best,
+        "workload": "population %d (reference: 20), 250 parameters, controller 5-16-8-2 in PyTorch (batched matmuls), "
+                    "index-progress fitness on the device; includes the host eigendecomposition" % N}
+    racers.venv.close()
+    log("callers: %s" % out)
+    return out
+
+
 def bench_evolution(args, ok, torch, dist, rank, world, local_rank, log):
     """BASELINE configs 3 and 4: full EvolutionaryRacer generations on the device, one island population per GPU."""
     from openkitchen_amd import sharding
@@ -292,6 +354,7 @@ def main():
 
     state = env.snapshot()
     crashed_frac = float(state["crashed"].mean())
+    callers = bench_callers(args, torch, local_rank, log) if (rank == 0 and world == 1 and not args.headline_only) else None
 
     if rank == 0:
         total_agents = N * world
@@ -337,6 +400,7 @@ def main():
             "value_one_launch_per_step": (N * one_steps / one_elapsed) if one_steps else None,
             "value_host_boundary_pcie_inclusive": (N * pcie_steps / pcie_elapsed) if pcie_steps else None,
             "crashed_fraction_at_end": crashed_frac,
+            "callers": callers,
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/hbm_traffic.json)",

@@ -82,7 +82,7 @@ enum okenv_field {
     /* rollout bookkeeping; exist after okenv_tracker_create (not part of okenv_state_view / snapshots) */
     OKENV_F_REWARD = 19,         /* f32  reward of the last okenv_tracker_update              */
     OKENV_F_FITNESS = 20,        /* f32  CmaEsAgent::fitness_ / return of the running episode  */
-    OKENV_F_TRACK_IDX = 21,      /* i32  prev_track_idx_ (main_eigen.cpp:84)                  */
+    OKENV_F_TRACK_IDX = 21,      /* i32  prev_track_idx_ (main_eigen.cpp:84); PROGRESS reward only, else 0 */
     OKENV_F_EPISODE_STEPS = 22,  /* u32  updates since the episode began                      */
     OKENV_F_EPISODE_RETURN = 23, /* f32  fitness at the end of the last finished episode     */
     OKENV_F_COUNT_ALL = 24
@@ -134,7 +134,8 @@ OKENV_API int okenv_set_sensor_offset(okenv_t h, float offset);
 /* Centre line + headings (RaceTrack::track_data_points_.x_m/y_m, headings_), needed by the nearest-index
  * query and by the on-device reset in okenv_rollout_random. */
 OKENV_API int okenv_set_centerline(okenv_t h, const float *x, const float *y, const float *heading_deg, int32_t num_points);
-/* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the private one. */
+/* Use an externally owned hipStream_t (e.g. torch's current stream, or a stream being captured into a hipGraph)
+ * instead of the private one.  Does not synchronise: ordering against work already queued is the caller's. */
 OKENV_API int okenv_set_stream(okenv_t h, void *hip_stream);
 OKENV_API int okenv_sync(okenv_t h);
 
@@ -174,7 +175,9 @@ OKENV_API int okenv_reset_random(okenv_t h, const int32_t *idx, int32_t n, uint3
  * it is the "initial observation" step callers take after a reset (RLRacers/PPO/ppo_sim.cpp:53-60).  The flags
  * of the crash stay readable until that next step. */
 OKENV_API int okenv_set_auto_reset(okenv_t h, int32_t enabled, uint32_t flags, uint32_t seed, uint32_t agent_base);
-/* Environment steps taken so far by okenv_step / okenv_rollout_policy on this handle (the auto-reset epoch). */
+/* Environment steps taken so far by okenv_step / okenv_rollout_policy on this handle (the auto-reset epoch).  While
+ * auto-reset is on the count lives on the device and is advanced on the stream behind every step, so a captured
+ * hipGraph of step launches replays with advancing epochs; reading it then synchronises. */
 OKENV_API int okenv_get_step_count(okenv_t h, uint32_t *out);
 OKENV_API int okenv_set_step_count(okenv_t h, uint32_t value);
 

@@ -59,7 +59,10 @@ struct okenv
     uint32_t    reset_flags{0}, reset_seed{0}, reset_agent_base{0}; // okenv_set_auto_reset
     OkTracker   tracker{};
     int         tracker_kind{-1};
-    uint32_t    step_count{0};                                      // Environment steps taken by okenv_step / okenv_rollout_policy
+    // Environment steps taken by okenv_step / okenv_rollout_policy.  While auto-reset is on the device copy is the
+    // authoritative one (it is the epoch of the reset draws and advances under graph replay); otherwise the host copy.
+    uint32_t    step_count{0};
+    uint32_t   *d_step_count{nullptr};
     OkDeviceState st{};
     std::vector<void *> allocations;
     int         block_threads{1024}, grid_blocks{1};
@@ -195,7 +198,7 @@ OkStepParams baseParams(okenv *h)
     p.reset_flags   = h->reset_flags;
     p.reset_seed    = h->reset_seed;
     p.agent_base    = h->reset_agent_base;
-    p.step_base     = h->step_count;
+    p.step_counter  = h->d_step_count;
     p.lane_l        = h->d_lane_l;
     p.lane_r        = h->d_lane_r;
     p.mlp_w         = h->d_mlp_w;
@@ -281,6 +284,14 @@ int launchStep(okenv *h, const OkStepParams &p)
 #undef OK_LAUNCH_GENERIC
     OK_HIP(h, hipGetLastError());
     return endTiming(h, ev);
+}
+
+// The step counter also lives on the device (it is the epoch of the auto-reset draws and must advance when a captured
+// graph of the step is replayed): okAdvanceStepCounter at the end of the step kernels.
+int advanceStepCount(okenv *h, const int n_steps)
+{
+    h->step_count += static_cast<uint32_t>(n_steps); // the device copy is advanced by the step kernel itself
+    return OKENV_OK;
 }
 
 int copyAny(okenv *h, void *dst, const void *src, const size_t bytes)
@@ -412,7 +423,8 @@ extern "C"
             (rc = devAlloc(h, &s.timed_out, N)) || (rc = devAlloc(h, &s.disp_to, N)) || (rc = devAlloc(h, &s.disp_ctr, N)) ||
             (rc = devAlloc(h, &s.disp_x, N)) || (rc = devAlloc(h, &s.disp_y, N)) || (rc = devAlloc(h, &s.hit_x, NR)) ||
             (rc = devAlloc(h, &s.hit_y, NR)) || (rc = devAlloc(h, &s.rel_x, NR)) || (rc = devAlloc(h, &s.rel_y, NR)) ||
-            (rc = devAlloc(h, &s.dist, NR)) || (rc = devAlloc(h, &h->d_ray_deg, static_cast<size_t>(num_rays))))
+            (rc = devAlloc(h, &s.dist, NR)) || (rc = devAlloc(h, &h->d_ray_deg, static_cast<size_t>(num_rays))) ||
+            (rc = devAlloc(h, &h->d_step_count, 2))) // [0] steps, [1] finished workgroups of the running launch
             return fail(nullptr, rc, h->last_error);
         OK_HIP(nullptr, hipMemcpyAsync(h->d_ray_deg, ray_angles_deg, 4U * num_rays, hipMemcpyHostToDevice, h->stream));
         h->host_ray_deg.assign(ray_angles_deg, ray_angles_deg + num_rays);
@@ -430,7 +442,7 @@ extern "C"
         { // tuning knob: smaller workgroups (two per CU when the LDS image allows)
             const long bt = std::atol(env_bt);
             if (bt >= 64 && bt <= 1024 && bt % 64 == 0 && bt % h->G == 0)
-                per_block = bt < per_block ? bt : per_block;
+                per_block = bt;
         }
         h->block_threads = static_cast<int>(per_block);
         h->grid_blocks   = static_cast<int>((total_lanes + per_block - 1) / per_block);
@@ -529,7 +541,8 @@ extern "C"
     {
         if (!h)
             return OKENV_ERR_INVALID;
-        OK_HIP(h, hipStreamSynchronize(h->stream));
+        // no synchronisation here: the call must be legal while the new stream is being captured into a graph; work
+        // already queued on the old stream completes on its own (hipStreamDestroy defers), ordering is the caller's
         if (h->own_stream && h->stream)
             (void)hipStreamDestroy(h->stream);
         h->stream     = static_cast<hipStream_t>(hip_stream);
@@ -713,13 +726,18 @@ extern "C"
     {
         if (!h)
             return OKENV_ERR_INVALID;
+        uint32_t count = 0;
+        int      rc    = okenv_get_step_count(h, &count); // folds the device copy back while it is still authoritative
+        if (rc != OKENV_OK)
+            return rc;
         if (!enabled)
         {
             h->reset_flags = 0;
             return OKENV_OK;
         }
-        const int rc = checkResetInputs(h, flags, "okenv_set_auto_reset");
-        if (rc != OKENV_OK)
+        if ((rc = checkResetInputs(h, flags, "okenv_set_auto_reset")) != OKENV_OK)
+            return rc;
+        if ((rc = okenv_set_step_count(h, count)) != OKENV_OK)
             return rc;
         h->reset_flags      = (flags & (OK_RESET_RANDOM_POINT | OK_RESET_RANDOM_LANE | OK_RESET_RANDOM_HEADING)) | kAutoResetOn;
         h->reset_seed       = seed;
@@ -731,6 +749,12 @@ extern "C"
     {
         if (!h || !out)
             return fail(h, OKENV_ERR_INVALID, "okenv_get_step_count: NULL argument");
+        if ((h->reset_flags & kAutoResetOn) != 0U)
+        {
+            OK_HIP(h, hipSetDevice(h->device));
+            OK_HIP(h, hipMemcpyAsync(&h->step_count, h->d_step_count, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            OK_HIP(h, hipStreamSynchronize(h->stream));
+        }
         *out = h->step_count;
         return OKENV_OK;
     }
@@ -740,6 +764,9 @@ extern "C"
         if (!h)
             return OKENV_ERR_INVALID;
         h->step_count = value;
+        OK_HIP(h, hipSetDevice(h->device));
+        OK_HIP(h, hipMemcpyAsync(h->d_step_count, &h->step_count, sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        OK_HIP(h, hipStreamSynchronize(h->stream));
         return OKENV_OK;
     }
 
@@ -802,9 +829,7 @@ extern "C"
         OkStepParams p = baseParams(h);
         p.n_steps      = n_steps;
         const int rc   = launchStep(h, p);
-        if (rc == OKENV_OK)
-            h->step_count += static_cast<uint32_t>(n_steps);
-        return rc;
+        return rc == OKENV_OK ? advanceStepCount(h, n_steps) : rc;
     }
 
     int okenv_collide(okenv_t h)
@@ -874,7 +899,8 @@ extern "C"
             dqx = dq;
             dqy = dq + n;
         }
-        hipLaunchKernelGGL(okNearestIdxKernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_cx, h->d_cy, h->P, dqx, dqy, n, dout);
+        hipLaunchKernelGGL(okNearestIdxKernel, dim3((n * kNearestLanes + 255) / 256), dim3(256), 0, h->stream, h->d_cx, h->d_cy, h->P, dqx, dqy, n,
+                           dout);
         OK_HIP(h, hipGetLastError());
         OK_HIP(h, hipMemcpyAsync(out, dout, 4U * n, hipMemcpyDefault, h->stream));
         if (dq)
@@ -913,8 +939,9 @@ extern "C"
         if (h->tracker_kind < 0)
             return fail(h, OKENV_ERR_STATE, std::string(who) + ": call okenv_tracker_create first");
         OK_HIP(h, hipSetDevice(h->device));
-        hipLaunchKernelGGL(okTrackerKernel, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->st, h->d_cx, h->d_cy, h->P, h->tracker,
-                           h->N, h->tracker_kind, begin);
+        const long threads = static_cast<long>(h->N) * (h->tracker_kind == kRewardProgress ? kNearestLanes : 1);
+        hipLaunchKernelGGL(okTrackerKernel, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, h->stream, h->st, h->d_cx, h->d_cy,
+                           h->P, h->tracker, h->N, h->tracker_kind, begin);
         OK_HIP(h, hipGetLastError());
         return OKENV_OK;
     }
@@ -993,9 +1020,7 @@ extern "C"
         p.n_steps       = n_steps;
         p.action_source = kActionsMlpPolicy;
         const int rc    = launchStep(h, p);
-        if (rc == OKENV_OK)
-            h->step_count += static_cast<uint32_t>(n_steps);
-        return rc;
+        return rc == OKENV_OK ? advanceStepCount(h, n_steps) : rc;
     }
 
     int okenv_alive_count(okenv_t h, int32_t *out)
@@ -1036,8 +1061,8 @@ extern "C"
         if (!h->d_mlp_w || h->P <= 0)
             return fail(h, OKENV_ERR_STATE, "okenv_ga_scores: needs okenv_policy_mlp_create and okenv_set_centerline");
         OK_HIP(h, hipSetDevice(h->device));
-        hipLaunchKernelGGL(okNearestIdxKernel, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->d_cx, h->d_cy, h->P, h->st.pos_x,
-                           h->st.pos_y, h->N, h->d_nearest);
+        hipLaunchKernelGGL(okNearestIdxKernel, dim3((h->N * kNearestLanes + 255) / 256), dim3(256), 0, h->stream, h->d_cx, h->d_cy, h->P,
+                           h->st.pos_x, h->st.pos_y, h->N, h->d_nearest);
         hipLaunchKernelGGL(okGaScoreKernel, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->d_nearest, h->d_score, h->N);
         OK_HIP(h, hipGetLastError());
         if (out)

@@ -82,6 +82,10 @@ struct OkStepParams
     // reset_flags = OK_RESET_* | kAutoResetOn, inner lane boundaries as xy pairs [P][2]
     uint32_t     reset_flags, reset_seed;
     const float *lane_l, *lane_r;
+    // epoch of the auto-reset draws: step_counter[0] + s.  Device-resident so that a captured hipGraph of the step
+    // replays with advancing epochs: the last workgroup to finish a launch adds n_steps (step_counter[1] counts the
+    // finished workgroups).
+    uint32_t *step_counter;
     // EvolutionaryRacer policy weights, OK_MLP_WEIGHTS(R) floats per agent (layout in okenv_math.h)
     const float *mlp_w;
     // RLRacers/Q_Learning: per-agent table [N][243][3], current state / action / previous track index, the five
@@ -156,9 +160,9 @@ __device__ __forceinline__ float okCastRay(const OkStepParams &p,
     }
 }
 
-// Stage the compact grid image into LDS with 16-byte loads (image_bytes is a multiple of 16).  Four loads are issued
+// Stage the compact grid image into LDS with 16-byte loads (image_bytes is a multiple of 16).  Eight loads are issued
 // back to back before their stores so that the L2 round trips overlap: with one launch per Environment step the
-// staging is a visible part of the launch.
+// staging is a visible part of the launch, and a small workgroup (few agents) has few lanes to spread it over.
 __device__ __forceinline__ void okStageImage(const OkStepParams &p, unsigned char *lds)
 {
     const uint4 *src = reinterpret_cast<const uint4 *>(p.image);
@@ -166,17 +170,38 @@ __device__ __forceinline__ void okStageImage(const OkStepParams &p, unsigned cha
     const int    n16 = static_cast<int>(p.image_bytes >> 4);
     const int    bd  = static_cast<int>(blockDim.x);
     int          i   = static_cast<int>(threadIdx.x);
-    for (; i + 3 * bd < n16; i += 4 * bd)
+    constexpr int kDepth = 8;
+    for (; i + (kDepth - 1) * bd < n16; i += kDepth * bd)
     {
-        const uint4 a = src[i], b = src[i + bd], c = src[i + 2 * bd], d = src[i + 3 * bd];
-        dst[i]          = a;
-        dst[i + bd]     = b;
-        dst[i + 2 * bd] = c;
-        dst[i + 3 * bd] = d;
+        uint4 v[kDepth];
+#pragma unroll
+        for (int k = 0; k < kDepth; ++k)
+            v[k] = src[i + k * bd];
+#pragma unroll
+        for (int k = 0; k < kDepth; ++k)
+            dst[i + k * bd] = v[k];
     }
     for (; i < n16; i += bd)
         dst[i] = src[i];
     __syncthreads();
+}
+
+// End of a step launch: advance the device-side step counter once, by the last workgroup to get here.  Every workgroup
+// has read the counter for the last time before its own arrival, so the writer runs after all readers.
+__device__ __forceinline__ void okAdvanceStepCounter(const OkStepParams &p)
+{
+    if ((p.reset_flags & 0x80000000U) == 0U)
+        return;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        __threadfence();
+        if (atomicAdd(&p.step_counter[1], 1U) == gridDim.x - 1U)
+        {
+            p.step_counter[0] += static_cast<uint32_t>(p.n_steps);
+            p.step_counter[1] = 0U;
+        }
+    }
 }
 
 // Per-agent state carried in registers across the steps of one launch (every lane of the agent's group holds a
@@ -240,7 +265,7 @@ __device__ __forceinline__ void okAgentPreStep(const OkStepParams &p, OkAgentReg
         // runs with the zeroed action, i.e. it is the "initial observation" step the callers take after a reset
         // (ppo_sim.cpp:58-60, main_eigen.cpp:127-128); DisplacementStats deliberately untouched
         const uint32_t      ag    = p.agent_base + static_cast<uint32_t>(a);
-        const uint32_t      epoch = p.step_base + static_cast<uint32_t>(s);
+        const uint32_t      epoch = p.step_counter[0] + static_cast<uint32_t>(s);
         const ok_reset_draw d     = ok_draw_reset(p.reset_seed, ag, epoch, ag + epoch, static_cast<uint32_t>(p.P), p.reset_flags);
         ok_reset_pose(d, p.cx, p.cy, p.chead, p.lane_l, p.lane_r, &r.pos_x, &r.pos_y, &r.rot);
         r.acc       = 0.F;
@@ -489,6 +514,7 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
     }
     if (agent_ok && rlane == 0)
         okStoreAgent(p.st, a, ag);
+    okAdvanceStepCounter(p);
 }
 
 // Workgroup-cooperative step kernel for the LDS form (one ray per lane).
@@ -737,6 +763,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
 #endif
     if (agent_ok && r == 0)
         okStoreAgent(p.st, a, ag);
+    okAdvanceStepCounter(p);
 }
 
 // ---- small service kernels ------------------------------------------------------------------------------
@@ -847,13 +874,18 @@ __global__ void okInitBenchKernel(OkDeviceState st, const float *cx, const float
     }
 }
 
-// RaceTrack::findNearestTrackIndexBruteForce (RaceTrack.cpp:16-31): one thread per query, centre line
-// staged in LDS in chunks; strict '<' so the lowest index wins ties, like the sequential scan.  Every thread of the
-// workgroup must call it (barriers inside); `sx`/`sy` are two 1024-float LDS arrays.
+// RaceTrack::findNearestTrackIndexBruteForce (RaceTrack.cpp:16-31).  kNearestLanes consecutive lanes share one query:
+// lane l scans the centre-line points l, l + L, l + 2L, ... of each LDS-staged chunk, then the lanes combine
+// (distance, index) pairs taking the smaller distance and, on equal distances, the lower index -- the element the
+// sequential strict-'<' scan keeps.  Every thread of the workgroup must call it (barriers inside); `sx`/`sy` are two
+// 1024-float LDS arrays; all lanes of a query receive the result.
+constexpr int kNearestLanes = 16;
+
 __device__ __forceinline__ int okNearestIdx(const float *cx, const float *cy, const int P, const float px, const float py, float *sx, float *sy)
 {
-    float bestv = 3.402823466e+38F; // FLT_MAX, as in the reference
-    int   arg   = 0;
+    const int lane  = static_cast<int>(threadIdx.x) & (kNearestLanes - 1);
+    float     bestv = 3.402823466e+38F; // FLT_MAX, as in the reference
+    int       arg   = 0x7FFFFFFF;
     for (int base = 0; base < P; base += 1024)
     {
         const int m = (P - base < 1024) ? (P - base) : 1024;
@@ -864,7 +896,7 @@ __device__ __forceinline__ int okNearestIdx(const float *cx, const float *cy, co
             sy[j] = cy[base + j];
         }
         __syncthreads();
-        for (int j = 0; j < m; ++j)
+        for (int j = lane; j < m; j += kNearestLanes)
         {
             const float dx = px - sx[j], dy = py - sy[j];
             const float d  = dx * dx + dy * dy;
@@ -875,16 +907,27 @@ __device__ __forceinline__ int okNearestIdx(const float *cx, const float *cy, co
             }
         }
     }
-    return arg;
+    for (int off = 1; off < kNearestLanes; off <<= 1)
+    {
+        const float ov = __shfl_xor(bestv, off, 64);
+        const int   oa = __shfl_xor(arg, off, 64);
+        if (ov < bestv || (ov == bestv && oa < arg))
+        {
+            bestv = ov;
+            arg   = oa;
+        }
+    }
+    // no point closer than FLT_MAX (NaN or infinite coordinates): the sequential scan answers index 0
+    return arg == 0x7FFFFFFF ? 0 : arg;
 }
 
 __global__ void okNearestIdxKernel(const float *cx, const float *cy, int P, const float *qx, const float *qy, int n, int32_t *out)
 {
     __shared__ float sx[1024], sy[1024];
-    const int        i  = blockIdx.x * blockDim.x + threadIdx.x;
-    const float      px = (i < n) ? qx[i] : 0.F, py = (i < n) ? qy[i] : 0.F;
+    const int        i   = (blockIdx.x * blockDim.x + threadIdx.x) / kNearestLanes;
+    const float      px  = (i < n) ? qx[i] : 0.F, py = (i < n) ? qy[i] : 0.F;
     const int        arg = okNearestIdx(cx, cy, P, px, py, sx, sy);
-    if (i < n)
+    if (i < n && (threadIdx.x & (kNearestLanes - 1)) == 0)
         out[i] = arg;
 }
 
@@ -906,14 +949,20 @@ enum OkRewardKind : int
     kRewardProgress = 1, // main_eigen.cpp:147-158
 };
 
-// The callers' loop body after env.step(), one thread per agent (begin != 0: the episode start of main_eigen.cpp:128-133).
+// The callers' loop body after env.step() (begin != 0: the episode start of main_eigen.cpp:128-133).  kNearestLanes
+// lanes per agent for the index-progress reward (they share the nearest-index scan, the first lane does the
+// bookkeeping); the +1 reward needs no track index and runs one thread per agent.
 __global__ void okTrackerKernel(OkDeviceState st, const float *cx, const float *cy, int P, OkTracker tr, int N, int kind, int begin)
 {
     __shared__ float sx[1024], sy[1024];
-    const int        i   = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool       ok  = i < N;
-    const int        idx = okNearestIdx(cx, cy, P, ok ? st.pos_x[i] : 0.F, ok ? st.pos_y[i] : 0.F, sx, sy);
-    if (!ok)
+    const int        lanes = (kind == kRewardProgress) ? kNearestLanes : 1;
+    const int        gid   = blockIdx.x * blockDim.x + threadIdx.x;
+    const int        i     = gid / lanes;
+    const bool       ok    = i < N;
+    int              idx   = 0;
+    if (kind == kRewardProgress)
+        idx = okNearestIdx(cx, cy, P, ok ? st.pos_x[i] : 0.F, ok ? st.pos_y[i] : 0.F, sx, sy);
+    if (!ok || gid % lanes != 0)
         return;
     const bool crashed = st.crashed[i] != 0;
     if (begin)

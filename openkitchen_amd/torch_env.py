@@ -91,6 +91,26 @@ class VectorEnvironment:
         """Enqueue the environment's kernels on `stream` (a torch.cuda.Stream) from now on."""
         self.env.set_stream(stream.cuda_stream)
 
+    def capture(self, body, warmup=3):
+        """Capture `body()` -- typically policy forward + `self.step(actions)` -- into a HIP graph and return it
+        (`graph.replay()` runs one iteration).  A loop of one Environment step per policy evaluation is launch-bound
+        (a dozen small kernels per iteration); replaying it as a graph removes the per-launch host cost.  The step
+        counter that seeds the auto-reset draws lives on the device, so replays keep advancing it.  `body` must not
+        synchronise or touch the host; the `warmup` eager iterations before the capture are real steps."""
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            self.use_stream(side)
+            for _ in range(warmup):
+                body()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            body()
+        self.use_stream(torch.cuda.current_stream(self.device))
+        return graph
+
     # ---- the reference binding's two methods, batched -------------------------------------------------------------
     def set_action(self, throttle_delta, steering_delta):
         """Agent::current_action_ of every agent; scalars or [N] tensors (Pybind/bindings.cpp:36-40)."""

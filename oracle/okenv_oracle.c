@@ -971,7 +971,8 @@ ORACLE_API void oracle_tracker_create(oracle_env *e, int kind)
 ORACLE_API void oracle_tracker_begin(oracle_env *e)
 {
     for (int a = 0; a < e->N; ++a) {
-        e->tr_prev_idx[a] = nearest_index(e, e->pos_x[a], e->pos_y[a]);
+        /* the +1 reward never reads the index (ppo_sim.cpp:82-86 is commented out): kept at 0 there */
+        e->tr_prev_idx[a] = e->tracker_kind == 1 ? nearest_index(e, e->pos_x[a], e->pos_y[a]) : 0;
         e->tr_fitness[a] = 0.0f; e->tr_reward[a] = 0.0f; e->tr_ep_steps[a] = 0;
         e->tr_prev_crashed[a] = e->crashed[a];
     }
@@ -986,7 +987,7 @@ ORACLE_API void oracle_tracker_update(oracle_env *e)
         float reward = 0.0f;
         if (was && !crashed) {
             e->tr_fitness[a] = 0.0f; e->tr_ep_steps[a] = 0;
-            e->tr_prev_idx[a] = nearest_index(e, e->pos_x[a], e->pos_y[a]);
+            e->tr_prev_idx[a] = e->tracker_kind == 1 ? nearest_index(e, e->pos_x[a], e->pos_y[a]) : 0;
         } else if (e->tracker_kind == 0) {
             reward = 1.0f;
             e->tr_fitness[a] += 1.0f;

@@ -87,3 +87,58 @@ def test_masked_reset_and_scalar_actions(gpu, oracle):
     moved = venv.pos_x != before
     assert moved[crashed].all()
     assert (venv.throttle[crashed] == 0).all() and (venv.throttle[~crashed] == 30).all()
+
+
+def test_graph_replay_matches_eager_and_oracle(gpu, oracle):
+    """policy + step + bookkeeping captured into one HIP graph: replays advance the device-side step counter (the
+    auto-reset epoch) and give the same bits as eager stepping and as the oracle fed the same actions."""
+    from openkitchen_amd.torch_env import VectorEnvironment
+    N, R, flags = 192, 5, 7
+    venv = VectorEnvironment("Austin", N, num_rays=R, seed=33, randomize_lane=True, randomize_heading=True, reward="progress")
+    orc = oracle_twin(oracle, venv, flags)
+    orc.tracker_create(1)
+    venv.reset()
+    orc.reset_random(None, flags, venv.seed, 0, venv.agent_base)
+    orc.step(1)
+    orc.tracker_begin()
+    w = torch.randn(R, 2, device="cuda")
+    log_thr = torch.zeros(64, N, device="cuda")
+    log_steer = torch.zeros(64, N, device="cuda")
+    it = torch.zeros((), dtype=torch.long, device="cuda")
+
+    def body():
+        out = torch.tanh(venv.observation() @ w)
+        thr, steer = 70 + 30 * out[:, 0], 5 * out[:, 1]
+        log_thr.index_copy_(0, it.view(1) % 64, thr.unsqueeze(0))
+        log_steer.index_copy_(0, it.view(1) % 64, steer.unsqueeze(0))
+        it.add_(1)
+        venv.step(torch.stack([thr, steer], dim=1))
+
+    def replay_oracle(n):
+        torch.cuda.synchronize()
+        lt, ls = log_thr.cpu().numpy(), log_steer.cpu().numpy()
+        for k in range(n):
+            orc.set(oracle.F_THR, lt[k])
+            orc.set(oracle.F_STEER, ls[k])
+            orc.step(1)
+            orc.tracker_update()
+
+    graph = venv.capture(body, warmup=3)  # 3 eager steps + the captured one (capture does not execute)
+    replay_oracle(3)
+    assert venv.env.step_count == orc.step_count == 4
+    it.zero_()
+    restarts = 0
+    for chunk in range(6):
+        it.zero_()
+        for _ in range(64):
+            graph.replay()
+        replay_oracle(64)
+        o = orc.snapshot()
+        assert np.array_equal(venv.distances.cpu().numpy().view(np.uint32), o["dist"].view(np.uint32)), chunk
+        assert np.array_equal(venv.pos_x.cpu().numpy().view(np.uint32), o["pos_x"].view(np.uint32)), chunk
+        assert np.array_equal(venv.crashed.cpu().numpy(), o["crashed"]), chunk
+        ot = orc.tracker_snapshot()
+        assert np.array_equal(venv.fitness.cpu().numpy().view(np.uint32), ot["fitness"].view(np.uint32)), chunk
+        restarts += int((ot["episode_steps"] < 64).sum())
+    assert venv.env.step_count == orc.step_count == 4 + 6 * 64
+    assert restarts > 0
