@@ -1,8 +1,16 @@
+"""Diagnostic: in-kernel phase timing of the cooperative step kernel (s_memtime stamps, OKENV_STAMPS build).
+
+Build the instrumented library first (not the product build):
+  hipcc -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt --offload-arch=gfx950 -fPIC -shared \
+        -fvisibility=hidden -Wno-unused-function -DOKENV_STAMPS -I include -I openkitchen_amd/csrc \
+        -o tools/_build/libokenv_stamps.so openkitchen_amd/csrc/okenv_capi.hip openkitchen_amd/csrc/facade/*.cpp
+Stamps: 0 pre-step, 1 phase 1, 2 barrier, 3 phase 2, 4 barrier, 5 epilogue (shader clock cycles per wave and step).
+"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, ".")
 import openkitchen_amd.buildlib as bl
-bl.LIB_PATH = os.path.abspath("experiments_tmp/libokenv_stamps.so")
+bl.LIB_PATH = os.path.abspath("tools/_build/libokenv_stamps.so")
 import openkitchen_amd as ok
 from openkitchen_amd import capi
 L = capi.load(build_if_missing=False)

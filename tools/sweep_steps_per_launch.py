@@ -1,3 +1,4 @@
+"""Diagnostic: per-launch fixed cost vs per-step cost of the step kernel for a few population shapes (run on the GPU box)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, ".")
