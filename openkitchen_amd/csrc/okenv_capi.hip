@@ -24,11 +24,8 @@ namespace
 thread_local std::string g_create_error = "";
 
 constexpr size_t kLdsBudget = 160U * 1024U; // one workgroup may take the whole CU's LDS on gfx950
-// LDS the cooperative kernel needs besides the image: 6 floats + 1 word per lane, 2 counters (okenv_kernels.h)
-constexpr size_t coopBytes(const size_t block_threads)
-{
-    return 28U * block_threads + 16U;
-}
+// LDS kept free behind the track image for the Q-learning kernel's copy of the centre line (8 B per point)
+constexpr size_t kLdsReserve = 16U * 1024U;
 
 struct EventPair
 {
@@ -77,7 +74,7 @@ struct okenv
     int      q_ray[5]{0, 0, 0, 0, 0};
     float    q_epsilon{0.F};
     std::vector<float> host_cx, host_cy, host_chead, host_ray_deg;
-    bool        coop{false};        // workgroup-cooperative two-phase kernel (LDS form, one ray per lane)
+    bool        coop{false};        // cooperative two-phase kernel (LDS form, one ray per lane)
     float       phase1_range{48.F}; // T1 of the cooperative kernel [px]
     std::string last_error;
     bool        timing{false};
@@ -261,7 +258,7 @@ int launchStep(okenv *h, const OkStepParams &p)
     case kGridLds:
         if (h->coop)
         {
-            const size_t   lds = h->image_bytes + coopBytes(h->block_threads);
+            const size_t   lds = h->image_bytes;
             const uint32_t off = static_cast<uint32_t>(h->image_bytes);
             if (p.action_source == kActionsQLearning)
                 hipLaunchKernelGGL(okStepCoopKernel<kPolicyQ>, grid, block, lds + 8U * static_cast<size_t>(h->P) + 16U, h->stream, p, off,
@@ -362,7 +359,7 @@ extern "C"
         // ---- grid ------------------------------------------------------------------------------------
         const OkSeg *segs = reinterpret_cast<const OkSeg *>(segments_xyxy);
         bool         fits = false;
-        h->grid = okBuildGridAuto(segs, static_cast<size_t>(num_segments), grid_cell, kLdsBudget - coopBytes(1024), &fits, &h->poly);
+        h->grid = okBuildGridAuto(segs, static_cast<size_t>(num_segments), grid_cell, kLdsBudget - kLdsReserve, &fits, &h->poly);
         if (flags & OKENV_FLAG_BRUTE_FORCE)
             h->grid_mode = kGridBrute;
         else if (!fits || (flags & OKENV_FLAG_FORCE_GLOBAL_GRID))
@@ -384,7 +381,7 @@ extern "C"
             h->d_image = dimg;
             OK_HIP(nullptr, hipMemcpyAsync(dimg, img.data(), h->image_bytes, hipMemcpyHostToDevice, h->stream));
             OK_HIP(nullptr, hipStreamSynchronize(h->stream));
-            const int lds_plain = static_cast<int>(h->image_bytes), lds_coop = static_cast<int>(h->image_bytes + coopBytes(1024));
+            const int lds_plain = static_cast<int>(h->image_bytes), lds_coop = lds_plain;
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepKernel<kGridLds, kPolicyNone>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_plain));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepKernel<kGridLds, kPolicyMlp>),
@@ -1172,7 +1169,7 @@ extern "C"
             return fail(h, OKENV_ERR_STATE, "okenv_rollout_q: call okenv_q_create first");
         if (n_steps == 0)
             return OKENV_OK;
-        if (h->image_bytes + coopBytes(h->block_threads) + 8U * static_cast<size_t>(h->P) + 16U > kLdsBudget)
+        if (h->image_bytes + 8U * static_cast<size_t>(h->P) + 16U > kLdsBudget)
             return fail(h, OKENV_ERR_STATE, "okenv_rollout_q: track image + centre line do not fit the CU's LDS");
         h->q_epsilon    = epsilon;
         OkStepParams p  = baseParams(h);

@@ -517,40 +517,35 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
     okAdvanceStepCounter(p);
 }
 
-// Workgroup-cooperative step kernel for the LDS form (one ray per lane).
+// Cooperative step kernel for the LDS form (one ray per lane).
 //
 // A fan's rays differ in length by an order of magnitude (median first hit ~25 px, sensor range 200 px), and a
 // wave costs as much as its longest ray, so with "each lane walks its own ray to the end" three quarters of the
-// lane-cycles idle.  Here the collision pass of a step runs in two phases:
+// lane-cycles idle.  Here the collision pass of a step runs in two phases, both inside the wave:
 //   phase 1  every lane walks its own ray over [0, T1] only (a few cells).  Most rays end there.
-//   phase 2  the unfinished rays of the whole workgroup are compacted into an LDS list and each is cut into m equal
-//            parameter intervals, m = min(8, lanes / unfinished); every (ray, interval) pair goes to one lane of the
-//            workgroup, which walks just that interval and folds its result into the ray's LDS slot with an LDS
-//            atomic min.  The intervals beyond a ray's true first hit are speculative work done by lanes that would
-//            otherwise idle; the critical path of a step drops from ~20 cells to ~4 + ~4.
+//   phase 2  the wave's unfinished rays (a ballot) are each cut into m equal parameter intervals,
+//            m = min(kMaxSplit, 64 / unfinished); lane L takes interval L % m of pending ray L / m -- origin, direction
+//            and progress come from the owner lane by ds_bpermute -- walks just that interval, the m lanes of a ray
+//            min-combine by shuffles and the owner pulls the result back.  The intervals beyond a ray's true first
+//            hit are speculative work done by lanes that would otherwise idle; the critical path of a step drops
+//            from ~20 cells to ~4 + ~3.
 // Exactness: ok_cast_poly_interval's contract (ok_raycast.h) -- the min over the intervals' results carries the same
-// bits as a single walk.  Two workgroup barriers per step; agents stay independent across workgroups.
+// bits as a single walk.  No workgroup barrier and no LDS traffic besides the track image: waves of a workgroup drift
+// apart freely, which is what hides their stalls (an earlier version compacted the unfinished rays of the whole
+// workgroup through LDS; its two barriers per step idled a quarter of the wave time).
 //
-// LDS: [ image | recs: 6 floats per lane | result: 1 word per lane | 2 counters ]
-struct OkCoopLds
-{
-    float    *rec;     // ox, oy, rdx, rdy, t_reached, owner lane (as int bits)
-    int      *result;  // first-hit parameter bits per owner lane (non-negative floats order like ints; -0.0 sorts first)
-    uint32_t *counter; // [2], alternating by step parity
-};
+// LDS: [ image | Q-learning only: centre line, 8 B per point ]
+#if !defined(OKENV_MAX_SPLIT)
+#define OKENV_MAX_SPLIT 8
+#endif
+constexpr int kMaxSplit = OKENV_MAX_SPLIT; // intervals a pending ray is cut into at most
 
 template <int kPolicy>
 __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, const uint32_t off_coop, const float phase1_range)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
-    OkCoopLds co;
-    co.rec     = reinterpret_cast<float *>(ok_lds + off_coop);
-    co.result  = reinterpret_cast<int *>(co.rec + 6 * blockDim.x);
-    co.counter = reinterpret_cast<uint32_t *>(co.result + blockDim.x);
-    if (threadIdx.x < 2)
-        co.counter[threadIdx.x] = 0U;
-    // Q-learning scans the centre line every step (reward = progress along it): keep it in LDS, after the counters
-    float *lds_cx = reinterpret_cast<float *>(co.counter + 4);
+    // Q-learning scans the centre line every step (reward = progress along it): keep it in LDS, behind the image
+    float *lds_cx = reinterpret_cast<float *>(ok_lds + off_coop);
     float *lds_cy = lds_cx + p.P;
     if (kPolicy == kPolicyQ)
     {
@@ -563,7 +558,6 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
     const OkPolyView view = okSetupView<kGridLds>(p, ok_lds); // ends with a barrier
 
     const int  G        = p.G;
-    const int  tid      = static_cast<int>(threadIdx.x);
     const long gl       = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
     const int  agent    = static_cast<int>(gl / G);
     const int  r        = static_cast<int>(gl % G);
@@ -599,7 +593,6 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
 #endif
     for (int s = 0; s < p.n_steps; ++s)
     {
-        const int par = s & 1;
         if (kPolicy == kPolicyMlp)
             okPolicyAction(p, a, r, G, ag, last_dist, ray_ok);
         if (kPolicy == kPolicyQ)
@@ -620,55 +613,70 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
         float       rdx = 1.F, rdy = 0.F;
 
         OK_STAMP(0);
-        // ---- phase 1: own ray over [0, T1] --------------------------------------------------------------
+        float min_t = OK_SENSOR_RANGE; // the ray's first-hit parameter
+        // ---- phase 1: own ray over [0, T1] ----------------------------------------------------------
+        bool  unfinished = false;
+        float t_reached  = 0.F;
         if (casts)
         {
             ok_sincosf(OK_DEG2RAD * (ag.rot + ray_deg), &rdy, &rdx);
             const OkIntervalResult r1 =
                 ok_cast_poly_interval<false>(view, ox, oy, rdx, rdy, 0.F, phase1_range, nullptr, nullptr, nullptr);
-            co.result[tid] = __float_as_int(r1.min_t);
-            if (!r1.conclusive)
-            {
-                const uint32_t slot = atomicAdd(&co.counter[par], 1U);
-                float         *rec  = co.rec + 6U * slot;
-                rec[0]              = ox;
-                rec[1]              = oy;
-                rec[2]              = rdx;
-                rec[3]              = rdy;
-                rec[4]              = r1.t_reached;
-                rec[5]              = __int_as_float(tid);
-            }
+            min_t      = r1.min_t;
+            unfinished = !r1.conclusive;
+            t_reached  = r1.t_reached;
         }
         OK_STAMP(1);
-        __syncthreads();
-        OK_STAMP(2);
-
-        // ---- phase 2: (unfinished ray, interval) pairs over all lanes of the workgroup ------------------------
-        const uint32_t unfinished = co.counter[par];
-        if (tid == 0)
-            co.counter[par ^ 1] = 0U; // next step's counter; nobody touches it until the next barrier
-        if (unfinished != 0U)
+        // ---- phase 2: the wave's unfinished rays, cut into m intervals each, over the wave's 64 lanes ------
+        const unsigned long long pending = __ballot(unfinished);
+        if (pending != 0ULL)
         {
-            uint32_t m = blockDim.x / unfinished;
-            m          = m > 8U ? 8U : m;
-            for (uint32_t task = tid; task < unfinished * m; task += blockDim.x)
+            const int lane = static_cast<int>(__lane_id());
+            const int n    = __popcll(pending);
+            int       m    = 64 / n;
+            m              = m > kMaxSplit ? kMaxSplit : m;
+            // rank of an unfinished lane among the pending ones; rank -> lane through a forward permute
+            const int rank  = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pending >> 32),
+                                                                         __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pending), 0U)));
+            // (pending lanes go to slots 0..n-1 in lane order, the others fill n..63: a bijection, so no two lanes
+            // write the same slot)
+            const int owner_of_rank = __builtin_amdgcn_ds_permute((unfinished ? rank : n + (lane - rank)) << 2, lane);
+            // task of this lane: interval j of pending ray q
+            // (lane + 0.5) / m is never within 1/16 of an integer, so the approximate reciprocal cannot misplace the floor
+            const float inv_m = okRcpApprox(static_cast<float>(m));
+            const int   q     = static_cast<int>((static_cast<float>(lane) + 0.5F) * inv_m);
+            const int  j      = lane - q * m;
+            const bool has    = q < n;
+            const int  owner  = __shfl(owner_of_rank, has ? q : 0, 64);
+            const float tox   = __shfl(ox, owner, 64);
+            const float toy   = __shfl(oy, owner, 64);
+            const float tdx   = __shfl(rdx, owner, 64);
+            const float tdy   = __shfl(rdy, owner, 64);
+            const float t0    = __shfl(t_reached, owner, 64);
+            float       found = OK_SENSOR_RANGE;
+            if (has)
             {
-                const uint32_t ray = task / m;
-                const uint32_t j   = task - ray * m;
-                const float   *rec = co.rec + 6U * ray;
-                const float    t0  = rec[4];
-                const float    dt  = (OK_SENSOR_RANGE - t0) / static_cast<float>(m);
-                const float    ta  = t0 + static_cast<float>(j) * dt;
-                const float    tb  = (j + 1U == m) ? OKRC_INF : t0 + static_cast<float>(j + 1U) * dt;
-                const OkIntervalResult r2 =
-                    ok_cast_poly_interval<false>(view, rec[0], rec[1], rec[2], rec[3], ta, tb, nullptr, nullptr, nullptr);
-                if (r2.min_t < OK_SENSOR_RANGE)
-                    atomicMin(&co.result[__float_as_int(rec[5])], __float_as_int(r2.min_t));
+                // neighbouring lanes evaluate the shared bound with the same expression, the last interval is open-ended:
+                // the intervals tile [t0, inf) whatever dt rounds to
+                const float dt = (OK_SENSOR_RANGE - t0) * inv_m;
+                const float ta = t0 + static_cast<float>(j) * dt;
+                const float tb = (j + 1 == m) ? OKRC_INF : t0 + static_cast<float>(j + 1) * dt;
+                const OkIntervalResult r2 = ok_cast_poly_interval<false>(view, tox, toy, tdx, tdy, ta, tb, nullptr, nullptr, nullptr);
+                found                     = r2.min_t;
             }
+            // min over the m lanes of a ray (consecutive lanes), then back to the owner
+#pragma unroll
+            for (int off = 1; off < kMaxSplit; off <<= 1)
+            {
+                const float other = __shfl_down(found, off, 64);
+                if (j + off < m && other < found)
+                    found = other;
+            }
+            const float mine = __shfl(found, unfinished ? rank * m : 0, 64);
+            if (unfinished && mine < min_t)
+                min_t = mine;
         }
         OK_STAMP(3);
-        __syncthreads();
-        OK_STAMP(4);
 
         // ---- hit point, transform, crash test (CollisionChecker.cu:69-70,144-172) -----------------------------------
         float min_d2 = OK_SENSOR_RANGE * OK_SENSOR_RANGE;
@@ -677,7 +685,6 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
             float hx, hy;
             if (casts)
             {
-                const float min_t = __int_as_float(co.result[tid]);
                 hx                = ox + min_t * rdx;
                 hy                = oy + min_t * rdy;
                 p.st.hit_x[k]     = hx;
