@@ -138,8 +138,8 @@ def bench_callers(args, torch, local_rank, log):
     dt = time.perf_counter() - t0
     out["cmaes_generation"] = {
         "value": N * gsteps / dt, "unit": "agent-steps/s", "generation_ms": dt * 1e3, "steps": gsteps, "best_fitness": best,
-        "workload": "population %d (reference: 20), 250 parameters, controller 5-16-8-2 in PyTorch (batched matmuls), "
-                    "index-progress fitness on the device; includes the host eigendecomposition" % N}
+        "workload": "population %d (reference: 20), 250 parameters, controller 5-16-8-2 in PyTorch, iteration replayed as one HIP "
+                    "graph, index-progress fitness on the device; includes sampling and the host eigendecomposition" % N}
     racers.venv.close()
     log("callers: %s" % out)
     return out

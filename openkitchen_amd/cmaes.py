@@ -2,7 +2,7 @@
 
 Mirror of the reference's CovarianceMatrixAdaptationEvolution app for N candidates at once:
   * `CmaEsSolver`      -- CmaEsSolverEigen.cpp:26-132 (host, float64; the rank-mu/rank-one update of arXiv:1604.00772)
-  * `BatchedController`-- Controller.cpp:3-23, one parameter vector per candidate, evaluated with batched matmuls
+  * `BatchedController`-- Controller.cpp:3-23, one parameter vector per candidate, evaluated for all candidates at once
   * `CmaEsRacers`      -- the generation loop of main_eigen.cpp:113-171: sample, resetAgent, one observation step, then
                           {updateAction; env.step(); fitness += |index progress|} until every candidate has crashed.
 The environment step and the fitness bookkeeping are libokenv.so kernels (okenv_step, okenv_tracker_update); the
@@ -17,7 +17,9 @@ from .torch_env import VectorEnvironment
 
 
 class CmaEsSolver:
-    def __init__(self, num_params, population_size, seed=0, sigma=0.5):
+    def __init__(self, num_params, population_size, seed=0, sigma=0.5, device=None):
+        """device: where the candidates are drawn and transformed (a torch device; None = numpy on the host).  The
+        250 x 250 state (mean, C, evolution paths) always lives on the host in float64."""
         n, lam = int(num_params), int(population_size)
         self.num_params, self.population_size, self.num_parents = n, lam, lam // 2
         self.sigma = float(sigma)
@@ -38,21 +40,33 @@ class CmaEsSolver:
         self.B = np.eye(n)
         self.D = np.ones(n)
         self.rng = np.random.default_rng(seed)
+        self.device = device
+        if device is not None:
+            self.generator = torch.Generator(device=device).manual_seed(int(seed))
 
     def sample(self):
         """Candidates x_i = mean + sigma * B (D * z_i), z_i ~ N(0, I); returns float32 [population, num_params]."""
         evals, self.B = np.linalg.eigh(self.C)
         self.D = np.sqrt(evals)
-        z = self.rng.standard_normal((self.population_size, self.num_params))
-        y = (z * self.D) @ self.B.T
-        return (self.mean + self.sigma * y).astype(np.float32)
+        if self.device is None:
+            z = self.rng.standard_normal((self.population_size, self.num_params))
+            y = (z * self.D) @ self.B.T
+            return (self.mean + self.sigma * y).astype(np.float32)
+        # population x n normals and the n x n rotation on the device (float64): with thousands of candidates this is
+        # the bulk of the solver's arithmetic
+        f64 = dict(dtype=torch.float64, device=self.device)
+        z = torch.randn(self.population_size, self.num_params, generator=self.generator, **f64)
+        y = (z * torch.as_tensor(self.D, **f64)) @ torch.as_tensor(self.B, **f64).T
+        return (torch.as_tensor(self.mean, **f64) + self.sigma * y).to(torch.float32)
 
     def tell(self, solutions, fitness):
         """Higher fitness is better (the reference sorts descending, CmaEsSolverEigen.cpp:86-90)."""
-        x = np.asarray(solutions, dtype=np.float64)
         order = np.argsort(-np.asarray(fitness, dtype=np.float64), kind="stable")[: self.num_parents]
+        if torch.is_tensor(solutions):  # only the parents travel to the host
+            parents = solutions[torch.as_tensor(order, device=solutions.device)].to(torch.float64).cpu().numpy()
+        else:
+            parents = np.asarray(solutions, dtype=np.float64)[order]
         old_mean = self.mean
-        parents = x[order]
         self.mean = self.weights @ parents
         y_w = (self.mean - old_mean) / self.sigma
         inv_sqrt_c = (self.B / self.D) @ self.B.T
@@ -70,32 +84,43 @@ class CmaEsSolver:
 class BatchedController:
     """tanh(fc3(tanh(fc2(tanh(fc1(x)))))) with fc1: in->h, fc2: h->h/2, fc3: h/2->out, one weight set per candidate.
     The flat parameter order is torch's `parameters()` order of the reference module: fc1.weight [h, in] row-major,
-    fc1.bias, fc2.weight, fc2.bias, fc3.weight, fc3.bias (Controller.cpp:36-53)."""
+    fc1.bias, fc2.weight, fc2.bias, fc3.weight, fc3.bias (Controller.cpp:36-53).  The parameters live in one
+    preallocated [population, num_params] tensor (`set_params` copies into it), so a captured graph of `forward`
+    stays valid across generations.  Layers are evaluated as broadcast multiply + sum: for 16x5 matrices that is
+    one small elementwise kernel, six times cheaper than a batched GEMM call."""
 
-    def __init__(self, input_size, hidden_size, output_size, device):
+    def __init__(self, input_size, hidden_size, output_size, device, population=None):
         self.sizes = [(hidden_size, input_size), (hidden_size // 2, hidden_size), (output_size, hidden_size // 2)]
         self.device = device
-        self.layers = None
+        self.flat = None if population is None else torch.zeros(population, self.count_params(), device=device)
+        self.layers = None if population is None else self._views()
 
     def count_params(self):
         return sum(o * i + o for o, i in self.sizes)
 
-    def set_params(self, flat):
-        flat = torch.as_tensor(flat, dtype=torch.float32, device=self.device)
-        assert flat.dim() == 2 and flat.shape[1] == self.count_params()
-        self.layers, off = [], 0
+    def _views(self):
+        layers, off = [], 0
         for o, i in self.sizes:
-            w = flat[:, off:off + o * i].reshape(-1, o, i)
+            w = self.flat[:, off:off + o * i].view(-1, o, i)
             off += o * i
-            b = flat[:, off:off + o].unsqueeze(2)
+            b = self.flat[:, off:off + o]
             off += o
-            self.layers.append((w, b))
+            layers.append((w, b))
+        return layers
+
+    def set_params(self, flat):
+        if not torch.is_tensor(flat):
+            flat = torch.from_numpy(np.ascontiguousarray(flat, dtype=np.float32))
+        assert flat.dim() == 2 and flat.shape[1] == self.count_params()
+        if self.flat is None or self.flat.shape != flat.shape:
+            self.flat = torch.empty(flat.shape, dtype=torch.float32, device=self.device)
+            self.layers = self._views()
+        self.flat.copy_(flat)  # host array or device tensor, straight into the preallocated buffer
 
     def forward(self, x):
-        x = x.unsqueeze(2)
         for w, b in self.layers:
-            x = torch.tanh(torch.baddbmm(b, w, x))
-        return x.squeeze(2)
+            x = torch.tanh((w * x.unsqueeze(1)).sum(dim=2) + b)
+        return x
 
 
 class CmaEsRacers:
@@ -106,27 +131,38 @@ class CmaEsRacers:
         self.venv = VectorEnvironment(track, population_size, ray_angles_deg=np.array(self.RAYS, dtype=np.float32),
                                       device=device, movement_mode=capi.MODE_VELOCITY, auto_reset=False,
                                       pick_random_point=reset_randomly, seed=seed, reward="progress")
-        self.controller = BatchedController(len(self.RAYS), self.HIDDEN, self.OUTPUTS, self.venv.device)
-        self.solver = CmaEsSolver(self.controller.count_params(), population_size, seed=seed)
+        self.controller = BatchedController(len(self.RAYS), self.HIDDEN, self.OUTPUTS, self.venv.device, population_size)
+        self.solver = CmaEsSolver(self.controller.count_params(), population_size, seed=seed, device=self.venv.device)
         self.max_steps = max_steps
         self.generation = 0
+        self._graph = None
 
     def update_action(self):
         """CmaEsAgent::updateAction (main_eigen.cpp:58-68): full throttle, steering = 5 * first output."""
         out = self.controller.forward(self.venv.observation())
         self.venv.set_action(100.0, out[:, 0] * 5.0)
 
-    def run_generation(self, check_every=16):
-        """One pass of the while(true) body, main_eigen.cpp:113-182; returns (best fitness, steps taken)."""
+    def _iteration(self):
+        self.update_action()
+        self.venv.step()
+
+    def run_generation(self, check_every=16, use_graph=True):
+        """One pass of the while(true) body, main_eigen.cpp:113-182; returns (best fitness, steps taken).  The loop
+        iteration (controller forward, env.step(), fitness bookkeeping: a dozen small kernels) is captured once into a
+        HIP graph and replayed; `use_graph=False` launches it eagerly."""
         venv = self.venv
         population = self.solver.sample()
         self.controller.set_params(population)
+        if use_graph and self._graph is None:
+            self._graph = venv.capture(self._iteration, warmup=2)
         # resetAgent for every candidate, the initial-observation step, prev_track_idx_ (main_eigen.cpp:120-133)
         venv.reset(epoch=self.generation)
         steps = 0
         while True:
-            self.update_action()
-            venv.step()
+            if use_graph:
+                self._graph.replay()
+            else:
+                self._iteration()
             steps += 1
             # crashed agents neither move nor score, so looking at the flags every few steps changes nothing
             if steps % check_every == 0 and venv.env.alive_count() == 0:

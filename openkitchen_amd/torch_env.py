@@ -40,7 +40,9 @@ class VectorEnvironment:
     FIELDS = {"pos_x": capi.F_POS_X, "pos_y": capi.F_POS_Y, "rot": capi.F_ROT, "speed": capi.F_SPEED,
               "acceleration": capi.F_ACC, "throttle": capi.F_THROTTLE, "steering": capi.F_STEER, "mode": capi.F_MODE,
               "crashed": capi.F_CRASHED, "timed_out": capi.F_TIMED_OUT, "hit_x": capi.F_HIT_X, "hit_y": capi.F_HIT_Y,
-              "rel_x": capi.F_REL_X, "rel_y": capi.F_REL_Y, "distances": capi.F_DIST}
+              "rel_x": capi.F_REL_X, "rel_y": capi.F_REL_Y, "distances": capi.F_DIST,
+              # DisplacementStats (the standstill bookkeeping, Environment.h:17-27)
+              "disp_ctr": capi.F_DISP_CTR, "disp_x": capi.F_DISP_X, "disp_y": capi.F_DISP_Y, "disp_timed_out": capi.F_DISP_TO}
     TRACKER_FIELDS = {"reward": capi.F_REWARD, "fitness": capi.F_FITNESS, "track_idx": capi.F_TRACK_IDX,
                       "episode_steps": capi.F_EPISODE_STEPS, "episode_return": capi.F_EPISODE_RETURN}
     SENSOR_RANGE = 200.0  # Agent::kSensorRange (Environment/Agent.h:10)
@@ -91,12 +93,21 @@ class VectorEnvironment:
         """Enqueue the environment's kernels on `stream` (a torch.cuda.Stream) from now on."""
         self.env.set_stream(stream.cuda_stream)
 
+    def _state_tensors(self):
+        names = list(self.FIELDS) + (list(self.TRACKER_FIELDS) if self.reward_kind is not None else [])
+        return {n: getattr(self, n) for n in names}
+
     def capture(self, body, warmup=3):
         """Capture `body()` -- typically policy forward + `self.step(actions)` -- into a HIP graph and return it
         (`graph.replay()` runs one iteration).  A loop of one Environment step per policy evaluation is launch-bound
         (a dozen small kernels per iteration); replaying it as a graph removes the per-launch host cost.  The step
         counter that seeds the auto-reset draws lives on the device, so replays keep advancing it.  `body` must not
-        synchronise or touch the host; the `warmup` eager iterations before the capture are real steps."""
+        synchronise or touch the host.  The `warmup` eager iterations that precede the capture (library and allocator
+        initialisation) run on a copy: the environment's state and step count are restored afterwards, so capturing
+        has no side effect on the simulation."""
+        torch.cuda.synchronize(self.device)
+        saved = {n: t.clone() for n, t in self._state_tensors().items()}
+        count = self.env.step_count
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -109,6 +120,10 @@ class VectorEnvironment:
         with torch.cuda.graph(graph, stream=side):
             body()
         self.use_stream(torch.cuda.current_stream(self.device))
+        for n, t in self._state_tensors().items():
+            t.copy_(saved[n])
+        self.env.step_count = count
+        torch.cuda.synchronize(self.device)
         return graph
 
     # ---- the reference binding's two methods, batched -------------------------------------------------------------

@@ -99,3 +99,18 @@ def test_discounted_returns_single_agent_equals_the_reference_loop():
     assert torch.allclose(got, want, atol=1e-5)
     raw = ro.discounted_returns(torch.ones(5, 3), 0.5, normalize=False)
     assert torch.allclose(raw[:, 1], torch.tensor([1.9375, 1.875, 1.75, 1.5, 1.0]))
+
+
+def test_solver_device_path_matches_host_update():
+    """sample()/tell() with a torch device (here the CPU device) against the numpy path fed the same candidates."""
+    cm = load_module("cmaes")
+    a = cm.CmaEsSolver(12, 16, seed=3, device=torch.device("cpu"))
+    b = cm.CmaEsSolver(12, 16, seed=3)
+    for _ in range(5):
+        xa = a.sample()
+        b.sample()  # advances b's eigendecomposition the same way
+        assert torch.is_tensor(xa) and xa.dtype == torch.float32 and xa.shape == (16, 12)
+        fit = -((xa.double().numpy() - 0.5) ** 2).sum(axis=1)
+        a.tell(xa, fit)
+        b.tell(xa.numpy(), fit)
+        assert np.allclose(a.mean, b.mean, atol=1e-12) and np.allclose(a.C, b.C, atol=1e-12) and np.isclose(a.sigma, b.sigma)

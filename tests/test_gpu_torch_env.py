@@ -123,9 +123,9 @@ def test_graph_replay_matches_eager_and_oracle(gpu, oracle):
             orc.step(1)
             orc.tracker_update()
 
-    graph = venv.capture(body, warmup=3)  # 3 eager steps + the captured one (capture does not execute)
-    replay_oracle(3)
-    assert venv.env.step_count == orc.step_count == 4
+    before = venv.pos_x.clone()
+    graph = venv.capture(body, warmup=3)  # warm-up iterations run, then everything they changed is restored
+    assert venv.env.step_count == orc.step_count == 1 and torch.equal(venv.pos_x, before)
     it.zero_()
     restarts = 0
     for chunk in range(6):
@@ -140,5 +140,5 @@ def test_graph_replay_matches_eager_and_oracle(gpu, oracle):
         ot = orc.tracker_snapshot()
         assert np.array_equal(venv.fitness.cpu().numpy().view(np.uint32), ot["fitness"].view(np.uint32)), chunk
         restarts += int((ot["episode_steps"] < 64).sum())
-    assert venv.env.step_count == orc.step_count == 4 + 6 * 64
+    assert venv.env.step_count == orc.step_count == 1 + 6 * 64
     assert restarts > 0

@@ -76,7 +76,7 @@ def test_cmaes_generation_fitness_matches_oracle_replay(gpu, oracle):
         return inner(actions, n_steps)
 
     venv.step = recording_step
-    best, steps = racers.run_generation(check_every=16)
+    best, steps = racers.run_generation(check_every=16, use_graph=False)
     assert steps == len(log) and steps >= 16
     fitness = venv.fitness.cpu().numpy()
     assert best == fitness.max() and best > 0
@@ -101,8 +101,23 @@ def test_cmaes_generation_fitness_matches_oracle_replay(gpu, oracle):
         assert venv.done.all()
     # the solver consumed that fitness: the mean moved, sigma changed
     assert np.abs(racers.solver.mean).max() > 0 and racers.solver.sigma != 0.5
-    best2, _ = racers.run_generation()
+    venv.step = inner
+    best2, _ = racers.run_generation()  # from here on as a replayed HIP graph
     assert racers.generation == 2 and best2 >= 0
+
+
+def test_cmaes_graph_replay_equals_eager(gpu):
+    """The captured iteration (controller forward + env.step + bookkeeping) gives the same fitness as eager launches,
+    generation after generation; capturing has no side effect on the simulation state."""
+    from openkitchen_amd.cmaes import CmaEsRacers
+    a = CmaEsRacers("Monza", 64, seed=11, max_steps=500)
+    b = CmaEsRacers("Monza", 64, seed=11, max_steps=500)
+    for g in range(3):
+        ba, sa = a.run_generation(use_graph=False)
+        bb, sb = b.run_generation(use_graph=True)
+        assert (ba, sa) == (bb, sb), g
+        assert np.array_equal(a.venv.fitness.cpu().numpy(), b.venv.fitness.cpu().numpy()), g
+        assert np.array_equal(a.venv.disp_ctr.cpu().numpy(), b.venv.disp_ctr.cpu().numpy()), g
 
 
 def test_collect_episode_shapes_and_semantics(gpu):
