@@ -3,6 +3,7 @@
 hipcc cross-compiles without a GPU, so this runs in the CPU-only development container as well as on the
 MI355X box.  The shared object is git-ignored but travels with the gpurun snapshot.
 """
+import fcntl
 import os
 import shutil
 import subprocess
@@ -51,12 +52,27 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
+    """Compiles libokenv.so if it is missing or older than its sources.  Safe to call from several processes at once
+    (one rank per GPU): an exclusive file lock serialises them, the check is repeated under the lock, and the new
+    library is moved into place atomically, so no rank ever loads a half-written file."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [_hipcc()] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB_PATH] + sources()
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True, cwd=ROOT)
+    with open(os.path.join(PKG_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or needs_build():
+                tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
+                cmd = [_hipcc()] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", tmp] + sources()
+                if verbose:
+                    print(" ".join(cmd), file=sys.stderr)
+                try:
+                    subprocess.run(cmd, check=True, cwd=ROOT)
+                    os.replace(tmp, LIB_PATH)
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
