@@ -396,6 +396,8 @@ def main():
                        "global_agents": total_agents, "steps_per_launch": spl, "parallelism": "dp%d (agent shards, no collective)" % world,
                        "grid_cell": info["grid_cell"], "lds_bytes": info["lds_bytes"]},
             "rays_per_sec": value * R,
+            # what the reference's sweep would have to evaluate for the same result: every ray against all S segments
+            "brute_force_equivalent_ray_segment_tests_per_sec": value * R * track.S,
             "valu_roofline": valu,
             "value_one_launch_per_step": (N * one_steps / one_elapsed) if one_steps else None,
             "value_host_boundary_pcie_inclusive": (N * pcie_steps / pcie_elapsed) if pcie_steps else None,
