@@ -46,6 +46,24 @@ WORKER = textwrap.dedent('''
     slow = sharding.max_over_ranks(1.0 + rank)
     assert slow == float(world)
     assert sharding.split_population(10, 3) == [(0, 4), (4, 3), (7, 3)]
+
+    # shareCumulativeKnowledge across ranks: sums and counts are all-reduced, every rank assigns the same means
+    class QStub:
+        def q_table_sums(self):
+            sums = np.full(729, 1.0 + rank, dtype=np.float32); counts = np.full(729, 2.0, dtype=np.float32)
+            sums[rank] = np.finfo(np.float32).min; counts[rank] = 0      # an entry this rank has never visited
+            sums[700:] = np.finfo(np.float32).min; counts[700:] = 0      # entries nobody has visited
+            return sums, counts
+        def q_assign_mean(self, sums, counts): self.got = (sums.copy(), counts.copy())
+        def q_share_knowledge(self): raise AssertionError("single-process path taken with world size 2")
+    q = QStub()
+    sharding.share_q_knowledge(q)
+    sums, counts = q.got
+    want_s = np.full(729, 3.0, dtype=np.float32); want_c = np.full(729, 4.0, dtype=np.float32)
+    want_s[0], want_c[0] = 2.0, 2.0    # only rank 1 contributed
+    want_s[1], want_c[1] = 1.0, 2.0    # only rank 0 contributed
+    want_s[700:], want_c[700:] = np.finfo(np.float32).min, 0.0
+    assert np.array_equal(sums, want_s) and np.array_equal(counts, want_c)
     if rank == 0:
         np.save(%(out)r, fit.numpy())
     dist.barrier()
