@@ -11,16 +11,19 @@
 class ScreenGrabber
 {
   public:
+    // what Pybind/bindings.cpp:62-68 exposes: int extents, RGBA8, bytes per row
     struct RenderTargetInfo
     {
-        size_t width{0};
-        size_t height{0};
-        size_t channels{4};
+        int width{0};
+        int height{0};
+        int channels{4};
+
+        size_t row_bytes() const { return static_cast<size_t>(width) * static_cast<size_t>(channels); }
     };
 
-    ScreenGrabber(size_t width, size_t height) : info_{width, height, 4} {}
+    ScreenGrabber(int width, int height) : info_{width, height, 4} {}
 
-    std::vector<uint8_t> getRenderTargetHost() const { return std::vector<uint8_t>(info_.width * info_.height * info_.channels, 0); }
+    std::vector<uint8_t> getRenderTargetHost() const { return std::vector<uint8_t>(info_.row_bytes() * static_cast<size_t>(info_.height), 0); }
     RenderTargetInfo     getRenderTargetInfo() const { return info_; }
     void                 saveRenderTargetToFile(const std::string & /*filename*/) const {}
 

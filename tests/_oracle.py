@@ -40,6 +40,8 @@ def build_oracle(with_ref=True):
     subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
     if with_ref and os.path.isdir("/root/reference/Environment"):
         subprocess.run(["make", "-s", "-C", ORACLE_DIR, "ref"], check=True)
+        if os.path.exists(os.path.join(ROOT, "openkitchen_amd", "libokenv.so")):
+            subprocess.run(["make", "-s", "-C", ORACLE_DIR, "refbind"], check=True)
 
 
 _lib = None

@@ -1,0 +1,42 @@
+"""Source-level drop-in of the reference's Python binding: oracle/Makefile's `refbind` target compiles the reference's
+own Pybind/bindings.cpp, unchanged and from where it lies, against this project's include/Environment/ headers and links
+it to libokenv.so (output oracle/_ref/open_kitchen_pybind*.so, git-ignored).  Where that module exists it must import
+and expose the reference's API; on a GPU it must run the reference's example loop (Pybind/example.py:10-20)."""
+import glob
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_module(ok):
+    paths = glob.glob(os.path.join(ROOT, "oracle", "_ref", "open_kitchen_pybind*.so"))
+    if not paths:
+        pytest.skip("oracle/_ref/open_kitchen_pybind*.so not built (needs /root/reference at build time)")
+    ok.capi.load()  # libokenv.so first, so that its HIP runtime is the one torch already loaded
+    spec = importlib.util.spec_from_file_location("open_kitchen_pybind", paths[0])
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_reference_bindings_compile_against_our_headers(ok, oracle):
+    mod = load_module(ok)
+    assert {"set_action", "step", "get_render_target", "get_render_target_info"} <= set(dir(mod.Environment))
+    assert {"width", "height", "channels", "row_bytes"} <= set(dir(mod.RenderTargetInfo))
+
+
+@pytest.mark.gpu
+def test_reference_example_loop_runs(gpu):
+    mod = load_module(gpu)
+    env = mod.Environment(gpu.track_path("Austin"), draw_rays=False, hidden_window=True)
+    for _ in range(50):
+        env.step()
+        env.set_action(30.0, 0.0)
+    info = env.get_render_target_info()
+    assert (info.width, info.height, info.channels) == (1600, 1400, 4) and info.row_bytes() == 6400
+    img = np.frombuffer(bytes(env.get_render_target()), dtype=np.uint8)
+    assert img.size == info.height * info.row_bytes()  # headless: the render target is blank
