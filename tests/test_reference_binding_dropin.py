@@ -40,3 +40,36 @@ def test_reference_example_loop_runs(gpu):
     assert (info.width, info.height, info.channels) == (1600, 1400, 4) and info.row_bytes() == 6400
     img = np.frombuffer(bytes(env.get_render_target()), dtype=np.uint8)
     assert img.size == info.height * info.row_bytes()  # headless: the render target is blank
+
+
+def run_app(name, track, seconds):
+    """Runs a reference application built by `make -C oracle refapps` for a while (they loop forever) and returns its
+    output; skips when the binary was not built."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", name)
+    if not os.path.exists(exe):
+        pytest.skip("%s not built (needs /root/reference at build time)" % exe)
+    try:
+        out = subprocess.run([exe, track], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=seconds).stdout
+        pytest.fail("the application ended on its own:\n" + out.decode()[-2000:])
+    except subprocess.TimeoutExpired as e:
+        return (e.stdout or b"").decode()
+
+
+@pytest.mark.gpu
+def test_reference_template_app_runs_on_the_device_environment(gpu):
+    """Template/main.cpp, unchanged: one agent, resetAgent + step in a loop, episodes end by crash or standstill."""
+    out = run_app("template_main", gpu.track_path("Austin"), 20)
+    episodes = out.count("EPISODE")
+    assert episodes >= 3, out[-1500:]
+
+
+@pytest.mark.gpu
+def test_reference_cmaes_app_runs_on_the_device_environment(gpu):
+    """CovarianceMatrixAdaptationEvolution/main_torch.cpp + its solver and controller, unchanged: 20 candidates per
+    generation driven through env.step() / findNearestTrackIndexBruteForce of this project's Environment."""
+    import re
+    out = run_app("cma_main_torch", gpu.track_path("Austin"), 40)
+    best = [float(x) for x in re.findall(r"Generation \d+ Best Fitness: ([0-9.eE+-]+)", out)]
+    assert len(best) >= 3, out[-1500:]
+    assert max(best) > 0
