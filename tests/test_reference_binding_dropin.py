@@ -42,16 +42,18 @@ def test_reference_example_loop_runs(gpu):
     assert img.size == info.height * info.row_bytes()  # headless: the render target is blank
 
 
-def run_app(name, track, seconds):
-    """Runs a reference application built by `make -C oracle refapps` for a while (they loop forever) and returns its
-    output; skips when the binary was not built."""
+def run_app(name, track, seconds, cwd=None, may_finish=False):
+    """Runs a reference application built by `make -C oracle refapps` for a while (most of them loop forever) and
+    returns its output; skips when the binary was not built."""
     import subprocess
     exe = os.path.join(ROOT, "oracle", "_ref", name)
     if not os.path.exists(exe):
         pytest.skip("%s not built (needs /root/reference at build time)" % exe)
     try:
-        out = subprocess.run([exe, track], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=seconds).stdout
-        pytest.fail("the application ended on its own:\n" + out.decode()[-2000:])
+        done = subprocess.run([exe, track], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=seconds, cwd=cwd)
+        if may_finish and done.returncode == 0:
+            return done.stdout.decode()
+        pytest.fail("the application ended on its own (rc %d):\n%s" % (done.returncode, done.stdout.decode()[-2000:]))
     except subprocess.TimeoutExpired as e:
         return (e.stdout or b"").decode()
 
@@ -73,3 +75,26 @@ def test_reference_cmaes_app_runs_on_the_device_environment(gpu):
     best = [float(x) for x in re.findall(r"Generation \d+ Best Fitness: ([0-9.eE+-]+)", out)]
     assert len(best) >= 3, out[-1500:]
     assert max(best) > 0
+
+
+@pytest.mark.gpu
+def test_reference_ddpg_app_runs_on_the_device_environment(gpu):
+    """RLRacers/DDPG/ddpg_sim.cpp + DDPGAgent.hpp, unchanged (its libtorch learner trains on the CPU between steps)."""
+    out = run_app("ddpg_sim", gpu.track_path("Austin"), 40)
+    assert out.count("EPISODE") >= 2, out[-1500:]
+
+
+@pytest.mark.gpu
+def test_reference_data_collector_runs_on_the_device_environment(gpu, tmp_path):
+    """FieldNavigators/collect_data/collect_data_random.cpp, unchanged: resetAgent with lane and heading randomisation,
+    a potential-field driver, one measurement file per step.  It looks for SaoPaulo.csv in a folder and writes into
+    ./SaoPaulo_random."""
+    import shutil
+    tracks = tmp_path / "tracks"
+    tracks.mkdir()
+    shutil.copy(gpu.track_path("Austin"), str(tracks / "SaoPaulo.csv"))
+    out = run_app("collect_data_random", str(tracks), 60, cwd=str(tmp_path), may_finish=True)  # ends after 200 goals
+    files = os.listdir(str(tmp_path / "SaoPaulo_random"))
+    assert len(files) > 50, out[-1500:]
+    throttle, steer = open(str(tmp_path / "SaoPaulo_random" / sorted(files)[0])).read().split()
+    assert abs(float(steer)) <= 10.0  # kSteeringAngleClampDeg
