@@ -378,6 +378,12 @@ int Environment::randomValue(const int lo, const int hi)
     return std::uniform_int_distribution<int>(lo, hi)(rng());
 }
 
+// headless stand-in for the drawing library's inclusive integer draw (Visualizer.h)
+int GetRandomValue(const int min, const int max)
+{
+    return std::uniform_int_distribution<int>(min, max)(rng());
+}
+
 int32_t Environment::pickRandomResetTrackIdx() const
 {
     return randomValue(0, static_cast<int32_t>(race_track_->track_data_points_.x_m.size()) - 1);

@@ -61,7 +61,7 @@ def run_app(name, track, seconds, cwd=None, may_finish=False):
 @pytest.mark.gpu
 def test_reference_template_app_runs_on_the_device_environment(gpu):
     """Template/main.cpp, unchanged: one agent, resetAgent + step in a loop, episodes end by crash or standstill."""
-    out = run_app("template_main", gpu.track_path("Austin"), 20)
+    out = run_app("template_main", gpu.track_path("Austin"), 10)
     episodes = out.count("EPISODE")
     assert episodes >= 3, out[-1500:]
 
@@ -71,7 +71,7 @@ def test_reference_cmaes_app_runs_on_the_device_environment(gpu):
     """CovarianceMatrixAdaptationEvolution/main_torch.cpp + its solver and controller, unchanged: 20 candidates per
     generation driven through env.step() / findNearestTrackIndexBruteForce of this project's Environment."""
     import re
-    out = run_app("cma_main_torch", gpu.track_path("Austin"), 40)
+    out = run_app("cma_main_torch", gpu.track_path("Austin"), 25)
     best = [float(x) for x in re.findall(r"Generation \d+ Best Fitness: ([0-9.eE+-]+)", out)]
     assert len(best) >= 3, out[-1500:]
     assert max(best) > 0
@@ -80,7 +80,7 @@ def test_reference_cmaes_app_runs_on_the_device_environment(gpu):
 @pytest.mark.gpu
 def test_reference_ddpg_app_runs_on_the_device_environment(gpu):
     """RLRacers/DDPG/ddpg_sim.cpp + DDPGAgent.hpp, unchanged (its libtorch learner trains on the CPU between steps)."""
-    out = run_app("ddpg_sim", gpu.track_path("Austin"), 40)
+    out = run_app("ddpg_sim", gpu.track_path("Austin"), 15)
     assert out.count("EPISODE") >= 2, out[-1500:]
 
 
@@ -98,3 +98,12 @@ def test_reference_data_collector_runs_on_the_device_environment(gpu, tmp_path):
     assert len(files) > 50, out[-1500:]
     throttle, steer = open(str(tmp_path / "SaoPaulo_random" / sorted(files)[0])).read().split()
     assert abs(float(steer)) <= 10.0  # kSteeringAngleClampDeg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("app", ["ppo_sim", "reinforce_sim"])
+def test_reference_policy_gradient_apps_run_on_the_device_environment(gpu, app):
+    """RLRacers/PPO/ppo_sim.cpp (+ PPOAgent.hpp, Actor/Critic, ExperienceBuffer) and RLRacers/Reinforce/reinforce_sim.cpp,
+    unchanged: 15 agents, resetAgent to random points, +1 reward per step, a libtorch update per episode."""
+    out = run_app(app, gpu.track_path("Austin"), 25)
+    assert out.count("EPISODE") >= 2, out[-1500:]
