@@ -2,7 +2,6 @@
 import sys
 import time
 
-import numpy as np
 
 sys.path.insert(0, ".")
 import openkitchen_amd as ok

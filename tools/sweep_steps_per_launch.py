@@ -1,6 +1,5 @@
 """Diagnostic: per-launch fixed cost vs per-step cost of the step kernel for a few population shapes (run on the GPU box)."""
-import os, sys, time
-import numpy as np
+import sys
 sys.path.insert(0, ".")
 import openkitchen_amd as ok
 t = ok.Track("Silverstone")
