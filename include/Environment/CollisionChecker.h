@@ -28,10 +28,11 @@ class OKENV_CLASS CollisionChecker
     const Ray_ *getHostRays() const;
     size_t      getNumRays() const;
 
-    // used by Environment: the underlying C-ABI handle, and the AoS <-> SoA exchange around a step
+    // used by Environment: the underlying C-ABI handle, and one whole Environment::step for `agents` (kinematics,
+    // standstill bookkeeping, collision pass) as a single packed exchange with the device.  The four arrays hold the
+    // agents' DisplacementStats members and are updated in place.
     okenv *handle() const;
-    void   uploadAgents(const std::vector<Agent *> &agents);
-    void   downloadAgents(const std::vector<Agent *> &agents);
+    void   stepAgents(const std::vector<Agent *> &agents, uint32_t *disp_ctr, float *disp_x, float *disp_y, uint8_t *disp_timed_out);
 
   private:
     class Impl;

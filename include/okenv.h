@@ -211,6 +211,26 @@ OKENV_API int okenv_get_hits(okenv_t h, float *out_xy);
 OKENV_API int okenv_get_distances(okenv_t h, float *out);
 OKENV_API int okenv_get_flags(okenv_t h, uint8_t *out);
 
+/* ---- packed host exchange for callers that keep Agent objects on the host (the C++ facade) -------------------- */
+
+/* One agent's mutable state as a record: the population crosses PCIe in ONE copy each way per step instead of one
+ * copy per field (Environment::step of the facade was 40 small copies = 370 us for a single agent before this). */
+typedef struct okenv_agent_record {
+    float    pos_x, pos_y, rot, speed, acc, throttle, steer; /* Agent::pos_, rot_, speed_, acceleration_, current_action_ */
+    float    disp_x, disp_y;                                 /* DisplacementStats::init_pos                              */
+    uint32_t disp_ctr;                                       /* DisplacementStats::displacement_ctr                      */
+    uint8_t  mode, crashed, timed_out, disp_timed_out;       /* movement_mode_, crashed_, timed_out_, displacement_timed_out */
+} okenv_agent_record;                                        /* 44 bytes */
+
+#define OKENV_PACKED_WITH_STATS 1u   /* the DisplacementStats members travel too (Environment::step); otherwise the   */
+                                     /* device keeps its own and the record's are left untouched                     */
+#define OKENV_PACKED_COLLIDE_ONLY 2u /* CollisionChecker::checkCollision(): no kinematics, no standstill bookkeeping  */
+/* Upload `in[num_agents]`, run one Environment::step (or only the collision pass), download the new state into
+ * `out[num_agents]` (may alias `in`) and Agent::sensor_hits_ as interleaved (x, y) pairs into sensor_hits_xy
+ * [num_agents * num_rays * 2].  Host pointers; synchronises. */
+OKENV_API int okenv_step_packed(okenv_t h, const okenv_agent_record *in, okenv_agent_record *out, float *sensor_hits_xy,
+                                uint32_t flags);
+
 /* ---- the hot path -------------------------------------------------------------------------------- */
 
 /* Environment::step() x n_steps (Environment/Environment.cpp:125-149, minus render): move + standstill for

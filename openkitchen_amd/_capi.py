@@ -44,7 +44,7 @@ SYMBOLS = [
     "okenv_q_table_sums", "okenv_q_assign_mean", "okenv_q_share_knowledge",
     "okenv_set_lane_bounds", "okenv_reset_random", "okenv_set_auto_reset", "okenv_get_step_count",
     "okenv_set_step_count", "okenv_field_device_ptr", "okenv_tracker_create", "okenv_tracker_begin",
-    "okenv_tracker_update",
+    "okenv_tracker_update", "okenv_step_packed",
 ]
 
 
@@ -144,6 +144,7 @@ def load(build_if_missing=True):
     L.okenv_set_auto_reset.argtypes = [vp, i32, u32, u32, u32]
     L.okenv_get_step_count.argtypes = [vp, C.POINTER(u32)]
     L.okenv_set_step_count.argtypes = [vp, u32]
+    L.okenv_step_packed.argtypes = [vp, vp, vp, vp, u32]
     L.okenv_tracker_create.argtypes = [vp, i32]
     L.okenv_tracker_begin.argtypes = [vp]
     L.okenv_tracker_update.argtypes = [vp]

@@ -92,96 +92,68 @@ class CollisionChecker::Impl
         if (okenv_create(&h_, reinterpret_cast<const float *>(host.data()), static_cast<int32_t>(num_segments), n_, r_,
                          agents[0]->sensor_ray_angles_.data(), device, OKENV_FLAG_NONE, 0.F) != OKENV_OK)
             die("okenv_create", nullptr);
-        const size_t n = static_cast<size_t>(n_);
-        for (auto *v : {&pos_x_, &pos_y_, &rot_, &speed_, &acc_, &thr_, &steer_, &disp_x_, &disp_y_})
-            v->assign(n, 0.F);
-        for (auto *v : {&mode_, &crashed_, &timed_out_, &disp_to_})
-            v->assign(n, 0);
-        disp_ctr_.assign(n, 0U);
-        hits_.assign(n * r_ * 2U, 0.F);
-        rays_.assign(n * r_, Ray_{0.F, 0.F, 0.F, 0.F, 0.F, true});
+        recs_.assign(static_cast<size_t>(n_), okenv_agent_record{});
+        hits_.assign(static_cast<size_t>(n_) * r_ * 2U, 0.F);
+        rays_.assign(static_cast<size_t>(n_) * r_, Ray_{0.F, 0.F, 0.F, 0.F, 0.F, true});
     }
 
     ~Impl() { okenv_destroy(h_); }
 
-    okenv_state_view view()
+    // Agent objects -> packed records -> device, one step (or only the collision pass), and back: two PCIe copies
+    // per call (okenv_step_packed).  The four `disp_*` arrays (optional) carry Environment's DisplacementStats.
+    void exchange(const std::vector<Agent *> &agents, const bool collide_only, uint32_t *disp_ctr, float *disp_x, float *disp_y,
+                  uint8_t *disp_to)
     {
-        okenv_state_view v{};
-        v.pos_x          = pos_x_.data();
-        v.pos_y          = pos_y_.data();
-        v.rot            = rot_.data();
-        v.speed          = speed_.data();
-        v.acc            = acc_.data();
-        v.throttle       = thr_.data();
-        v.steer          = steer_.data();
-        v.mode           = mode_.data();
-        v.crashed        = crashed_.data();
-        v.timed_out      = timed_out_.data();
-        v.disp_ctr       = disp_ctr_.data();
-        v.disp_x         = disp_x_.data();
-        v.disp_y         = disp_y_.data();
-        v.disp_timed_out = disp_to_.data();
-        return v;
-    }
-
-    // Agent objects -> staging -> device.  `stats` (optional) carries Environment's DisplacementStats.
-    void upload(const std::vector<Agent *> &agents, const std::vector<DisplacementStats> *stats)
-    {
+        const bool with_stats = disp_ctr != nullptr;
         for (int i = 0; i < n_; ++i)
         {
-            const Agent *a = agents[i];
-            pos_x_[i]      = a->pos_.x;
-            pos_y_[i]      = a->pos_.y;
-            rot_[i]        = a->rot_;
-            speed_[i]      = a->speed_;
-            acc_[i]        = a->acceleration_;
-            thr_[i]        = a->current_action_.throttle_delta;
-            steer_[i]      = a->current_action_.steering_delta;
-            mode_[i]       = static_cast<uint8_t>(a->movement_mode_);
-            crashed_[i]    = a->crashed_ ? 1 : 0;
-            timed_out_[i]  = a->timed_out_ ? 1 : 0;
-            if (stats)
+            const Agent        *a = agents[i];
+            okenv_agent_record &r = recs_[static_cast<size_t>(i)];
+            r.pos_x               = a->pos_.x;
+            r.pos_y               = a->pos_.y;
+            r.rot                 = a->rot_;
+            r.speed               = a->speed_;
+            r.acc                 = a->acceleration_;
+            r.throttle            = a->current_action_.throttle_delta;
+            r.steer               = a->current_action_.steering_delta;
+            r.mode                = static_cast<uint8_t>(a->movement_mode_);
+            r.crashed             = a->crashed_ ? 1 : 0;
+            r.timed_out           = a->timed_out_ ? 1 : 0;
+            if (with_stats)
             {
-                disp_ctr_[i] = (*stats)[i].displacement_ctr;
-                disp_x_[i]   = (*stats)[i].init_pos.x;
-                disp_y_[i]   = (*stats)[i].init_pos.y;
-                disp_to_[i]  = (*stats)[i].displacement_timed_out ? 1 : 0;
+                r.disp_ctr       = disp_ctr[i];
+                r.disp_x         = disp_x[i];
+                r.disp_y         = disp_y[i];
+                r.disp_timed_out = disp_to[i];
             }
         }
         if (okenv_set_sensor_offset(h_, agents[0]->sensor_offset_) != OKENV_OK)
             die("okenv_set_sensor_offset", h_);
-        okenv_state_view v = view();
-        if (!stats)
-            v.disp_ctr = nullptr, v.disp_x = nullptr, v.disp_y = nullptr, v.disp_timed_out = nullptr;
-        if (okenv_upload_state(h_, &v) != OKENV_OK)
-            die("okenv_upload_state", h_);
-    }
-
-    void download(const std::vector<Agent *> &agents, std::vector<DisplacementStats> *stats)
-    {
-        okenv_state_view v = view();
-        if (okenv_download_state(h_, &v) != OKENV_OK || okenv_get_hits(h_, hits_.data()) != OKENV_OK)
-            die("okenv_download_state", h_);
+        const uint32_t flags = (with_stats ? OKENV_PACKED_WITH_STATS : 0U) | (collide_only ? OKENV_PACKED_COLLIDE_ONLY : 0U);
+        if (okenv_step_packed(h_, recs_.data(), recs_.data(), hits_.data(), flags) != OKENV_OK)
+            die("okenv_step_packed", h_);
         for (int i = 0; i < n_; ++i)
         {
-            Agent *a         = agents[i];
-            a->pos_          = {pos_x_[i], pos_y_[i]};
-            a->rot_          = rot_[i];
-            a->speed_        = speed_[i];
-            a->acceleration_ = acc_[i];
-            a->crashed_      = crashed_[i] != 0;
-            a->timed_out_    = timed_out_[i] != 0;
+            Agent                    *a = agents[i];
+            const okenv_agent_record &r = recs_[static_cast<size_t>(i)];
+            a->pos_                     = {r.pos_x, r.pos_y};
+            a->rot_                     = r.rot;
+            a->speed_                   = r.speed;
+            a->acceleration_            = r.acc;
+            a->crashed_                 = r.crashed != 0;
+            a->timed_out_               = r.timed_out != 0;
             a->sensor_hits_.resize(static_cast<size_t>(r_));
-            for (int r = 0; r < r_; ++r)
+            for (int q = 0; q < r_; ++q)
             {
-                const size_t k     = (static_cast<size_t>(i) * r_ + r) * 2U;
-                a->sensor_hits_[r] = {hits_[k], hits_[k + 1]};
+                const size_t k     = (static_cast<size_t>(i) * r_ + q) * 2U;
+                a->sensor_hits_[q] = {hits_[k], hits_[k + 1]};
             }
-            if (stats)
+            if (with_stats)
             {
-                (*stats)[i].displacement_ctr       = disp_ctr_[i];
-                (*stats)[i].init_pos               = {disp_x_[i], disp_y_[i]};
-                (*stats)[i].displacement_timed_out = disp_to_[i] != 0;
+                disp_ctr[i] = r.disp_ctr;
+                disp_x[i]   = r.disp_x;
+                disp_y[i]   = r.disp_y;
+                disp_to[i]  = r.disp_timed_out;
             }
         }
         rays_valid_ = false;
@@ -220,10 +192,9 @@ class CollisionChecker::Impl
     okenv_t              h_{nullptr};
     std::vector<Agent *> agents_;
     int                  n_{0}, r_{0};
-    std::vector<float>    pos_x_, pos_y_, rot_, speed_, acc_, thr_, steer_, disp_x_, disp_y_, hits_;
-    std::vector<uint8_t>  mode_, crashed_, timed_out_, disp_to_;
-    std::vector<uint32_t> disp_ctr_;
-    std::vector<Ray_>     rays_;
+    std::vector<okenv_agent_record> recs_;
+    std::vector<float>              hits_;
+    std::vector<Ray_>               rays_;
     bool                  rays_valid_{false};
 };
 
@@ -236,10 +207,7 @@ CollisionChecker::~CollisionChecker() = default;
 
 void CollisionChecker::checkCollision()
 {
-    impl_->upload(impl_->agents_, nullptr);
-    if (okenv_collide(impl_->h_) != OKENV_OK)
-        die("okenv_collide", impl_->h_);
-    impl_->download(impl_->agents_, nullptr);
+    impl_->exchange(impl_->agents_, true, nullptr, nullptr, nullptr, nullptr);
 }
 
 const Ray_ *CollisionChecker::getHostRays() const
@@ -257,64 +225,12 @@ okenv *CollisionChecker::handle() const
     return impl_->h_;
 }
 
-void CollisionChecker::uploadAgents(const std::vector<Agent *> &agents)
+void CollisionChecker::stepAgents(const std::vector<Agent *> &agents, uint32_t *disp_ctr, float *disp_x, float *disp_y, uint8_t *disp_timed_out)
 {
-    impl_->upload(agents, nullptr);
-}
-
-void CollisionChecker::downloadAgents(const std::vector<Agent *> &agents)
-{
-    impl_->download(agents, nullptr);
+    impl_->exchange(agents, false, disp_ctr, disp_x, disp_y, disp_timed_out);
 }
 
 // ---- Environment --------------------------------------------------------------------------------------------
-
-namespace
-{
-// Environment needs the Impl's stats-carrying exchange; CollisionChecker.h keeps Impl private, so the two calls go
-// through this friend-free shim: a second state view uploaded/downloaded straight over the C ABI.
-struct StatsExchange
-{
-    std::vector<uint32_t> ctr;
-    std::vector<float>    x, y;
-    std::vector<uint8_t>  to;
-
-    void upload(okenv_t h, const std::vector<DisplacementStats> &s)
-    {
-        const size_t n = s.size();
-        ctr.resize(n), x.resize(n), y.resize(n), to.resize(n);
-        for (size_t i = 0; i < n; ++i)
-        {
-            ctr[i] = s[i].displacement_ctr;
-            x[i]   = s[i].init_pos.x;
-            y[i]   = s[i].init_pos.y;
-            to[i]  = s[i].displacement_timed_out ? 1 : 0;
-        }
-        okenv_state_view v{};
-        v.disp_ctr = ctr.data(), v.disp_x = x.data(), v.disp_y = y.data(), v.disp_timed_out = to.data();
-        if (okenv_upload_state(h, &v) != OKENV_OK)
-            die("okenv_upload_state(stats)", h);
-    }
-    void download(okenv_t h, std::vector<DisplacementStats> &s)
-    {
-        okenv_state_view v{};
-        v.disp_ctr = ctr.data(), v.disp_x = x.data(), v.disp_y = y.data(), v.disp_timed_out = to.data();
-        if (okenv_download_state(h, &v) != OKENV_OK)
-            die("okenv_download_state(stats)", h);
-        for (size_t i = 0; i < s.size(); ++i)
-        {
-            s[i].displacement_ctr       = ctr[i];
-            s[i].init_pos               = {x[i], y[i]};
-            s[i].displacement_timed_out = to[i] != 0;
-        }
-    }
-};
-StatsExchange &statsExchange()
-{
-    static thread_local StatsExchange ex;
-    return ex;
-}
-} // namespace
 
 Environment::Environment(const std::string &race_track_path, const std::vector<Agent *> &agents, const bool draw_rays, const bool hidden_window)
     : draw_rays_(draw_rays)
@@ -358,13 +274,25 @@ void Environment::drawSensorRanges(const std::vector<Vec2d> & /*sensor_hits*/) {
 void Environment::step()
 {
     ensureChecker();
-    okenv_t h = collision_checker_->handle();
-    collision_checker_->uploadAgents(agents_);
-    statsExchange().upload(h, displacement_stats_);
-    if (okenv_step(h, 1) != OKENV_OK)
-        die("okenv_step", h);
-    collision_checker_->downloadAgents(agents_);
-    statsExchange().download(h, displacement_stats_);
+    // DisplacementStats travel with the agents: members -> flat arrays -> device -> back
+    const size_t          n = agents_.size();
+    std::vector<uint32_t> ctr(n);
+    std::vector<float>    ix(n), iy(n);
+    std::vector<uint8_t>  to(n);
+    for (size_t i = 0; i < n; ++i)
+    {
+        ctr[i] = displacement_stats_[i].displacement_ctr;
+        ix[i]  = displacement_stats_[i].init_pos.x;
+        iy[i]  = displacement_stats_[i].init_pos.y;
+        to[i]  = displacement_stats_[i].displacement_timed_out ? 1 : 0;
+    }
+    collision_checker_->stepAgents(agents_, ctr.data(), ix.data(), iy.data(), to.data());
+    for (size_t i = 0; i < n; ++i)
+    {
+        displacement_stats_[i].displacement_ctr       = ctr[i];
+        displacement_stats_[i].init_pos               = {ix[i], iy[i]};
+        displacement_stats_[i].displacement_timed_out = to[i] != 0;
+    }
     visualizer_->render(*race_track_, agents_, draw_rays_ ? collision_checker_.get() : nullptr);
 }
 

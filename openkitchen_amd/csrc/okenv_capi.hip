@@ -54,6 +54,9 @@ struct okenv
     float      *d_lane_l{nullptr}, *d_lane_r{nullptr}; // left_bound_inner_ / right_bound_inner_, xy pairs
     int         lane_points{0}, lane_capacity{0};
     uint32_t    reset_flags{0}, reset_seed{0}, reset_agent_base{0}; // okenv_set_auto_reset
+    // packed host exchange (okenv_step_packed): pinned host staging + device records, allocated on first use
+    void       *h_stage{nullptr};
+    void       *d_stage{nullptr};
     OkTracker   tracker{};
     int         tracker_kind{-1};
     // Environment steps taken by okenv_step / okenv_rollout_policy.  While auto-reset is on the device copy is the
@@ -465,6 +468,8 @@ extern "C"
         (void)hipStreamSynchronize(h->stream);
         for (void *p : h->allocations)
             (void)hipFree(p);
+        if (h->h_stage)
+            (void)hipHostFree(h->h_stage);
         for (auto &e : h->events)
         {
             (void)hipEventDestroy(e.start);
@@ -827,6 +832,66 @@ extern "C"
         p.n_steps      = n_steps;
         const int rc   = launchStep(h, p);
         return rc == OKENV_OK ? advanceStepCount(h, n_steps) : rc;
+    }
+
+    int okenv_step_packed(okenv_t h, const okenv_agent_record *in, okenv_agent_record *out, float *sensor_hits_xy, uint32_t flags)
+    {
+        if (!h || !in || !out || !sensor_hits_xy)
+            return fail(h, OKENV_ERR_INVALID, "okenv_step_packed: NULL argument");
+        OK_HIP(h, hipSetDevice(h->device));
+        const size_t N = static_cast<size_t>(h->N), NR = N * static_cast<size_t>(h->R);
+        const size_t rec_bytes = N * sizeof(okenv_agent_record), hit_bytes = NR * 2U * sizeof(float);
+        const size_t out_off   = (rec_bytes + 255U) & ~static_cast<size_t>(255U); // [ in records | out records | hits ]
+        const size_t hit_off   = 2U * out_off;
+        if (!h->h_stage)
+        {
+            OK_HIP(h, hipHostMalloc(&h->h_stage, hit_off + hit_bytes, hipHostMallocDefault));
+            uint8_t *d = nullptr;
+            const int rc = devAlloc(h, &d, hit_off + hit_bytes);
+            if (rc != OKENV_OK)
+                return rc;
+            h->d_stage = d;
+        }
+        uint8_t *hs = static_cast<uint8_t *>(h->h_stage), *ds = static_cast<uint8_t *>(h->d_stage);
+        std::memcpy(hs, in, rec_bytes);
+        OK_HIP(h, hipMemcpyAsync(ds, hs, rec_bytes, hipMemcpyHostToDevice, h->stream));
+        const unsigned blocks_n = static_cast<unsigned>((N + 255U) / 256U);
+        hipLaunchKernelGGL(okUnpackRecordsKernel, dim3(blocks_n), dim3(256), 0, h->stream, h->st,
+                           reinterpret_cast<const okenv_agent_record *>(ds), h->N, (flags & OKENV_PACKED_WITH_STATS) ? 1 : 0);
+        OkStepParams p = baseParams(h);
+        if (flags & OKENV_PACKED_COLLIDE_ONLY)
+        {
+            p.do_move     = 0;
+            p.reset_flags = 0;
+        }
+        int rc = launchStep(h, p);
+        if (rc != OKENV_OK)
+            return rc;
+        if ((flags & OKENV_PACKED_COLLIDE_ONLY) == 0U)
+            advanceStepCount(h, 1);
+        const size_t threads = NR > N ? NR : N;
+        hipLaunchKernelGGL(okPackRecordsKernel, dim3(static_cast<unsigned>((threads + 255U) / 256U)), dim3(256), 0, h->stream, h->st,
+                           reinterpret_cast<okenv_agent_record *>(ds + out_off), reinterpret_cast<float *>(ds + hit_off), h->N, h->R);
+        OK_HIP(h, hipGetLastError());
+        OK_HIP(h, hipMemcpyAsync(hs + out_off, ds + out_off, (hit_off - out_off) + hit_bytes, hipMemcpyDeviceToHost, h->stream));
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        if ((flags & OKENV_PACKED_WITH_STATS) != 0U)
+            std::memcpy(out, hs + out_off, rec_bytes);
+        else
+        { // the caller's DisplacementStats members stay as they were
+            const okenv_agent_record *src = reinterpret_cast<const okenv_agent_record *>(hs + out_off);
+            for (size_t i = 0; i < N; ++i)
+            {
+                okenv_agent_record r = src[i];
+                r.disp_x             = in[i].disp_x;
+                r.disp_y             = in[i].disp_y;
+                r.disp_ctr           = in[i].disp_ctr;
+                r.disp_timed_out     = in[i].disp_timed_out;
+                out[i]               = r;
+            }
+        }
+        std::memcpy(sensor_hits_xy, hs + hit_off, hit_bytes);
+        return OKENV_OK;
     }
 
     int okenv_collide(okenv_t h)

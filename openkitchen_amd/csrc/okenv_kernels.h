@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/okenv.h"
 #include "ok_raycast.h"
 
 struct OkDeviceState
@@ -774,6 +775,63 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
 }
 
 // ---- small service kernels ------------------------------------------------------------------------------
+
+// Packed host exchange (okenv_step_packed): records <-> struct-of-arrays, one thread per agent; the pack side also
+// interleaves sensor_hits_ as (x, y) pairs, one thread per ray.
+__global__ void okUnpackRecordsKernel(OkDeviceState st, const okenv_agent_record *rec, int N, int with_stats)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= N)
+        return;
+    const okenv_agent_record r = rec[a];
+    st.pos_x[a]     = r.pos_x;
+    st.pos_y[a]     = r.pos_y;
+    st.rot[a]       = r.rot;
+    st.speed[a]     = r.speed;
+    st.acc[a]       = r.acc;
+    st.thr[a]       = r.throttle;
+    st.steer[a]     = r.steer;
+    st.mode[a]      = r.mode;
+    st.crashed[a]   = r.crashed;
+    st.timed_out[a] = r.timed_out;
+    if (with_stats)
+    {
+        st.disp_x[a]   = r.disp_x;
+        st.disp_y[a]   = r.disp_y;
+        st.disp_ctr[a] = r.disp_ctr;
+        st.disp_to[a]  = r.disp_timed_out;
+    }
+}
+
+__global__ void okPackRecordsKernel(OkDeviceState st, okenv_agent_record *rec, float *hits_xy, int N, int R)
+{
+    const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < static_cast<long>(N) * R)
+    {
+        hits_xy[2 * i]     = st.rel_x[i];
+        hits_xy[2 * i + 1] = st.rel_y[i];
+    }
+    if (i < N)
+    {
+        const int          a = static_cast<int>(i);
+        okenv_agent_record r;
+        r.pos_x          = st.pos_x[a];
+        r.pos_y          = st.pos_y[a];
+        r.rot            = st.rot[a];
+        r.speed          = st.speed[a];
+        r.acc            = st.acc[a];
+        r.throttle       = st.thr[a];
+        r.steer          = st.steer[a];
+        r.disp_x         = st.disp_x[a];
+        r.disp_y         = st.disp_y[a];
+        r.disp_ctr       = st.disp_ctr[a];
+        r.mode           = st.mode[a];
+        r.crashed        = st.crashed[a];
+        r.timed_out      = st.timed_out[a];
+        r.disp_timed_out = st.disp_to[a];
+        rec[a]           = r;
+    }
+}
 
 // Agent::reset for a list of agents (Agent.cpp:123-135).
 __global__ void okResetKernel(OkDeviceState st, const int32_t *idx, const float *x, const float *y, const float *rot, int n, int N)
