@@ -101,6 +101,18 @@ def test_rollout_random_bit_exact(gpu, oracle, track_name, N, R, mode):
         assert crashes > 0, "the trajectory must exercise crashes"
 
 
+def test_long_trajectory_bit_exact(gpu, oracle):
+    """BASELINE config 1 (64 agents x 16 rays, Austin) for 3000 steps of the bench driver loop: thousands of crashes and
+    resets and many standstill periods later the state is still the oracle's, bit for bit."""
+    t, dev, orc = make_pair(gpu, oracle, "Austin", 64, 16)
+    dev.init_bench_state(0, 0)
+    orc.init_bench_state(0, 0)
+    for chunk in range(6):
+        dev.rollout_random(500, 4321, 0, chunk * 500)
+        orc.rollout_random(500, 4321, 0, chunk * 500, threads=8)
+        assert_same_state(dev.snapshot(), orc.snapshot(), "after %d steps" % ((chunk + 1) * 500))
+
+
 def test_host_actions_step_by_step(gpu, oracle):
     """The Environment::step surface proper: host writes actions, one launch per step; agents crash and are
     left crashed (stale rays), one agent is reset by the host mid-way, standstill timeouts fire."""
