@@ -349,14 +349,23 @@ extern "C"
         OK_HIP(nullptr, hipSetDevice(device));
         OK_HIP(nullptr, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 
-        // lanes per agent
-        h->G             = pow2ceil(num_rays) > 64 ? 64 : pow2ceil(num_rays);
+        // lanes per agent: the fan's width rounded up to a power of two -- and more when the population is far too
+        // small to fill the machine: the spare lanes of an agent's group take intervals of its rays in phase 2, which
+        // shortens the dependent chain of a step (11.5-13 us instead of 15.6 us per step for RL-sized populations).
+        // Kept to half of the machine's 256 x 1024 lanes so that the waves of a CU do not start competing for issue.
+        h->G = pow2ceil(num_rays) > 64 ? 64 : pow2ceil(num_rays);
+        const int natural_g = h->G;
+        while (h->G < 64 && static_cast<long>(num_agents) * (2L * h->G) <= 131072L)
+            h->G *= 2;
         if (const char *env_g = std::getenv("OKENV_LANES_PER_AGENT"))
-        { // tuning knob: fold the fan over fewer lanes (ray r, r+G, r+2G, ... share a lane)
+        { // tuning knob: fold the fan over fewer lanes (ray r, r+G, r+2G, ... share a lane) or spread it over more
             const int g = std::atoi(env_g);
-            if (g >= 1 && g <= 64 && (g & (g - 1)) == 0 && g <= h->G)
+            if (g >= 1 && g <= 64 && (g & (g - 1)) == 0)
                 h->G = g;
         }
+        // with spare lanes phase 1 only clears the origin's surroundings; the splitting of phase 2 does the rest
+        if (h->G > natural_g)
+            h->phase1_range = 4.F;
         h->rays_per_lane = (num_rays + h->G - 1) / h->G;
 
         // ---- grid ------------------------------------------------------------------------------------
@@ -1024,7 +1033,7 @@ extern "C"
     {
         if (!h || hidden < 1 || hidden > OK_MLP_HID_PAD)
             return fail(h, OKENV_ERR_INVALID, "okenv_policy_mlp_create: hidden width must be in [1, 32]");
-        if (h->rays_per_lane != 1 || h->G < 8)
+        if (h->rays_per_lane != 1 || h->R < 5 || h->G < 8)
             return fail(h, OKENV_ERR_INVALID, "okenv_policy_mlp_create: the fused policy needs 5 <= rays <= 64");
         OK_HIP(h, hipSetDevice(h->device));
         const size_t total = static_cast<size_t>(h->N) * OK_MLP_WEIGHTS(h->R);
