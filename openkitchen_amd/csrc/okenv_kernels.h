@@ -258,7 +258,15 @@ __device__ __forceinline__ void okStoreAgent(const OkDeviceState &st, const int 
 // sin/cos(kDeg2Rad * rot_) of the pose the collision pass will see: Agent::move, the ray build and the hit transform
 // all take the sine and cosine of that same angle (Agent.cpp:94-97, CollisionChecker.cu:121-124,157-158), so it is
 // evaluated once per agent and step.
-__device__ __forceinline__ void okAgentPreStep(const OkStepParams &p, OkAgentRegs &r, const int a, const int s, float &sn, float &cs)
+__device__ __forceinline__ void okAgentPreStep(const OkStepParams &p,
+                                               OkAgentRegs        &r,
+                                               const int           a,
+                                               const int           s,
+                                               float              &sn,
+                                               float              &cs,
+                                               const float         ray_deg = 0.F,
+                                               float              *ray_sn  = nullptr,
+                                               float              *ray_cs  = nullptr)
 {
     if ((p.reset_flags & kAutoResetOn) != 0U && r.crashed)
     {
@@ -312,6 +320,11 @@ __device__ __forceinline__ void okAgentPreStep(const OkStepParams &p, OkAgentReg
             r.speed = (r.speed > OK_SPEED_LIMIT) ? OK_SPEED_LIMIT : r.speed;
         }
     }
+    // The lane's ray direction (CollisionChecker.cu:125, angle = kDeg2Rad * (rot_ + ray angle)) depends on nothing but
+    // the heading just updated: evaluated here, next to the agent's own sine/cosine, the two independent fp64 chains
+    // interleave instead of running back to back.
+    if (ray_sn != nullptr)
+        ok_sincosf(OK_DEG2RAD * (r.rot + ray_deg), ray_sn, ray_cs);
     ok_sincosf(OK_DEG2RAD * r.rot, &sn, &cs);
     if (moves)
     {
@@ -607,11 +620,11 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
             ok_q_action_values(q_action, &ag.thr, &ag.steer);
         }
         float sr, cr;
-        okAgentPreStep(p, ag, a, s, sr, cr);
+        float rdx = 1.F, rdy = 0.F;
+        okAgentPreStep(p, ag, a, s, sr, cr, ray_deg, &rdy, &rdx);
         const float ox     = ag.pos_x + p.sensor_offset * cr;
         const float oy     = ag.pos_y + p.sensor_offset * sr;
         const bool  casts  = ray_ok && !ag.crashed;
-        float       rdx = 1.F, rdy = 0.F;
 
         OK_STAMP(0);
         float min_t = OK_SENSOR_RANGE; // the ray's first-hit parameter
@@ -620,7 +633,6 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
         float t_reached  = 0.F;
         if (casts)
         {
-            ok_sincosf(OK_DEG2RAD * (ag.rot + ray_deg), &rdy, &rdx);
             const OkIntervalResult r1 =
                 ok_cast_poly_interval<false>(view, ox, oy, rdx, rdy, 0.F, phase1_range, nullptr, nullptr, nullptr);
             min_t      = r1.min_t;
