@@ -17,7 +17,7 @@
 //     those G lanes, no LDS, no atomics.
 //   * the track is staged ONCE per workgroup into LDS as the compact "poly" image of ok_grid.h: a cell-major
 //     stream of boundary points (8 B each, shared by chained segments) + an 8-byte header per grid cell,
-//     90-115 KB for the config tracks; every point evaluation and ray-segment test then reads LDS,
+//     75-95 KB for the config tracks; every point evaluation and ray-segment test then reads LDS,
 //     never HBM.  Adjacent rays of a fan start in the same cell and fan out slowly, so most LDS reads of a
 //     wave-instruction hit the same few addresses (broadcast).
 //   * agent state is struct-of-arrays in HBM, read once at launch into registers, carried across the
