@@ -74,6 +74,9 @@ struct okenv
     float   *d_q_table{nullptr};
     int32_t *d_q_state{nullptr}, *d_q_action{nullptr}, *d_q_prev{nullptr}, *d_q_reset_nearest{nullptr};
     float   *d_q_sums{nullptr};
+    uint16_t *d_cl_start{nullptr}, *d_cl_idx{nullptr}; // centre line bucketed by grid cell (Q-learning's nearest index)
+    size_t    cl_capacity{0};
+    bool      cl_dirty{true};
     int      q_ray[5]{0, 0, 0, 0, 0};
     float    q_epsilon{0.F};
     std::vector<float> host_cx, host_cy, host_chead, host_ray_deg;
@@ -209,6 +212,8 @@ OkStepParams baseParams(okenv *h)
     for (int i = 0; i < 5; ++i)
         p.q_ray[i] = h->q_ray[i];
     p.q_epsilon = h->q_epsilon;
+    p.cl_start  = h->cl_dirty ? nullptr : h->d_cl_start;
+    p.cl_idx    = h->cl_dirty ? nullptr : h->d_cl_idx;
     return p;
 }
 
@@ -239,6 +244,64 @@ int endTiming(okenv *h, const EventPair &ev)
     return OKENV_OK;
 }
 
+// LDS the Q-learning kernel needs behind the track image: the centre line (8 B per point) and its cell buckets
+size_t qLdsBytes(const okenv *h)
+{
+    const size_t cells = static_cast<size_t>(h->grid.g.nx) * h->grid.g.ny;
+    return 8U * static_cast<size_t>(h->P) + 2U * (cells + 1U) + 2U * static_cast<size_t>(h->P) + 16U;
+}
+
+// Buckets the centre-line points by the cells of the raycast grid (CSR, indices ascending inside a cell) and uploads
+// them; a centre line with more than 65535 points keeps the full scan.
+int buildCenterlineBuckets(okenv *h)
+{
+    if (!h->cl_dirty)
+        return OKENV_OK;
+    const OkGridGeom &g     = h->grid.g;
+    const size_t      cells = static_cast<size_t>(g.nx) * g.ny;
+    if (h->P <= 0 || h->P > 65535)
+        return OKENV_OK; // stays dirty: the kernel scans the whole line
+    std::vector<uint16_t> start(cells + 1U, 0), idx(static_cast<size_t>(h->P));
+    std::vector<int>      cell_of(static_cast<size_t>(h->P));
+    std::vector<uint32_t> count(cells, 0U);
+    for (int i = 0; i < h->P; ++i)
+    {
+        // same arithmetic as the kernel's lookup; points outside the grid go to the nearest border cell, which only
+        // makes their bucket a superset
+        int ci = static_cast<int>((h->host_cx[i] - g.x0) * g.inv_cell), cj = static_cast<int>((h->host_cy[i] - g.y0) * g.inv_cell);
+        ci     = ci < 0 ? 0 : (ci >= g.nx ? g.nx - 1 : ci);
+        cj     = cj < 0 ? 0 : (cj >= g.ny ? g.ny - 1 : cj);
+        cell_of[i] = cj * g.nx + ci;
+        ++count[static_cast<size_t>(cell_of[i])];
+    }
+    uint32_t run = 0;
+    for (size_t c = 0; c < cells; ++c)
+    {
+        start[c] = static_cast<uint16_t>(run);
+        run += count[c];
+    }
+    start[cells] = static_cast<uint16_t>(run);
+    std::vector<uint32_t> fill(cells, 0U);
+    for (int i = 0; i < h->P; ++i)
+    {
+        const size_t c                = static_cast<size_t>(cell_of[i]);
+        idx[start[c] + fill[c]++] = static_cast<uint16_t>(i);
+    }
+    const size_t need = cells + 1U + static_cast<size_t>(h->P);
+    if (need > h->cl_capacity)
+    {
+        int rc;
+        if ((rc = devAlloc(h, &h->d_cl_start, cells + 1U)) || (rc = devAlloc(h, &h->d_cl_idx, static_cast<size_t>(h->P))))
+            return rc;
+        h->cl_capacity = need;
+    }
+    OK_HIP(h, hipMemcpyAsync(h->d_cl_start, start.data(), 2U * (cells + 1U), hipMemcpyHostToDevice, h->stream));
+    OK_HIP(h, hipMemcpyAsync(h->d_cl_idx, idx.data(), 2U * static_cast<size_t>(h->P), hipMemcpyHostToDevice, h->stream));
+    OK_HIP(h, hipStreamSynchronize(h->stream));
+    h->cl_dirty = false;
+    return OKENV_OK;
+}
+
 int launchStep(okenv *h, const OkStepParams &p)
 {
     OK_HIP(h, hipSetDevice(h->device));
@@ -264,7 +327,7 @@ int launchStep(okenv *h, const OkStepParams &p)
             const size_t   lds = h->image_bytes;
             const uint32_t off = static_cast<uint32_t>(h->image_bytes);
             if (p.action_source == kActionsQLearning)
-                hipLaunchKernelGGL(okStepCoopKernel<kPolicyQ>, grid, block, lds + 8U * static_cast<size_t>(h->P) + 16U, h->stream, p, off,
+                hipLaunchKernelGGL(okStepCoopKernel<kPolicyQ>, grid, block, lds + qLdsBytes(h), h->stream, p, off,
                                    h->phase1_range);
             else if (policy == kPolicyMlp)
                 hipLaunchKernelGGL(okStepCoopKernel<kPolicyMlp>, grid, block, lds, h->stream, p, off, h->phase1_range);
@@ -536,7 +599,8 @@ extern "C"
                 return rc;
             h->centerline_capacity = num_points;
         }
-        h->P = num_points;
+        h->P        = num_points;
+        h->cl_dirty = true;
         h->host_cx.resize(num_points), h->host_cy.resize(num_points), h->host_chead.resize(num_points);
         OK_HIP(h, hipMemcpy(h->host_cx.data(), x, 4U * num_points, hipMemcpyDefault));
         OK_HIP(h, hipMemcpy(h->host_cy.data(), y, 4U * num_points, hipMemcpyDefault));
@@ -1243,8 +1307,12 @@ extern "C"
             return fail(h, OKENV_ERR_STATE, "okenv_rollout_q: call okenv_q_create first");
         if (n_steps == 0)
             return OKENV_OK;
-        if (h->image_bytes + 8U * static_cast<size_t>(h->P) + 16U > kLdsBudget)
+        if (h->image_bytes + qLdsBytes(h) > kLdsBudget)
             return fail(h, OKENV_ERR_STATE, "okenv_rollout_q: track image + centre line do not fit the CU's LDS");
+        OK_HIP(h, hipSetDevice(h->device));
+        const int brc = buildCenterlineBuckets(h);
+        if (brc != OKENV_OK)
+            return brc;
         h->q_epsilon    = epsilon;
         OkStepParams p  = baseParams(h);
         p.n_steps       = n_steps;

@@ -93,6 +93,9 @@ struct OkStepParams
     // rays that feed the state, epsilon of this rollout
     float   *q_table;
     int32_t *q_state, *q_action, *q_prev_idx;
+    // centre-line points bucketed by the cells of `geom` (CSR: point indices of cell c are cl_idx[cl_start[c] ..
+    // cl_start[c + 1]), ascending); nullptr: scan the whole centre line every step
+    const uint16_t *cl_start, *cl_idx;
     int      q_ray[5];
     float    q_epsilon;
 };
@@ -559,14 +562,23 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
     // Q-learning scans the centre line every step (reward = progress along it): keep it in LDS, behind the image
-    float *lds_cx = reinterpret_cast<float *>(ok_lds + off_coop);
-    float *lds_cy = lds_cx + p.P;
+    float    *lds_cx     = reinterpret_cast<float *>(ok_lds + off_coop);
+    float    *lds_cy     = lds_cx + p.P;
+    uint16_t *lds_cstart = reinterpret_cast<uint16_t *>(lds_cy + p.P);
+    uint16_t *lds_cidx   = lds_cstart + (p.geom.nx * p.geom.ny + 1);
     if (kPolicy == kPolicyQ)
     {
         for (int i = threadIdx.x; i < p.P; i += blockDim.x)
         {
             lds_cx[i] = p.cx[i];
             lds_cy[i] = p.cy[i];
+        }
+        if (p.cl_start != nullptr)
+        {
+            for (int i = threadIdx.x; i <= p.geom.nx * p.geom.ny; i += blockDim.x)
+                lds_cstart[i] = p.cl_start[i];
+            for (int i = threadIdx.x; i < p.P; i += blockDim.x)
+                lds_cidx[i] = p.cl_idx[i];
         }
     }
     const OkPolyView view = okSetupView<kGridLds>(p, ok_lds); // ends with a barrier
@@ -723,28 +735,79 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
                 next_state += ok_q_bin(__shfl(last_dist, p.q_ray[i], G)) * mult;
                 mult *= 3;
             }
-            // RaceTrack::findNearestTrackIndexBruteForce, the agent's G lanes striding over the centre line; strict '<'
-            // per lane and (distance, index) order across lanes keep the sequential scan's "lowest index wins"
+            // RaceTrack::findNearestTrackIndexBruteForce.  The centre line is bucketed by grid cell: the agent's lanes look
+            // at the 3 x 3 cells around its position first; if the best point found there is closer than the block's
+            // nearest edge, no point outside can beat or tie it and the result is the brute-force argmin (strict '<' per
+            // lane over ascending indices, (distance, index) order across lanes: "lowest index wins").  Otherwise -- an
+            // agent far from the track -- the lanes stride over the whole centre line as before.
             float best = 3.402823466e+38F;
             int   bi   = 0x7FFFFFFF;
-            for (int i = r; i < p.P; i += G)
+            bool  done = false;
+            if (p.cl_start != nullptr)
             {
-                const float dx = ag.pos_x - lds_cx[i], dy = ag.pos_y - lds_cy[i];
-                const float d2 = dx * dx + dy * dy;
-                if (d2 < best)
+                const OkGridGeom &g  = p.geom;
+                const int         ci = static_cast<int>((ag.pos_x - g.x0) * g.inv_cell), cj = static_cast<int>((ag.pos_y - g.y0) * g.inv_cell);
+                if (ag.pos_x >= g.x0 && ag.pos_y >= g.y0 && ci < g.nx && cj < g.ny)
                 {
-                    best = d2;
-                    bi   = i;
+                    for (int c = r; c < 9; c += G)
+                    {
+                        const int ix = ci + (c % 3) - 1, iy = cj + (c / 3) - 1;
+                        if (ix < 0 || iy < 0 || ix >= g.nx || iy >= g.ny)
+                            continue;
+                        const int cell = iy * g.nx + ix;
+                        for (int k = lds_cstart[cell]; k < lds_cstart[cell + 1]; ++k)
+                        {
+                            const int   i  = lds_cidx[k];
+                            const float dx = ag.pos_x - lds_cx[i], dy = ag.pos_y - lds_cy[i];
+                            const float d2 = dx * dx + dy * dy;
+                            if (d2 < best)
+                            {
+                                best = d2;
+                                bi   = i;
+                            }
+                        }
+                    }
+                    for (int off = 1; off < G; off <<= 1)
+                    {
+                        const float ob = __shfl_xor(best, off, 64);
+                        const int   oi = __shfl_xor(bi, off, 64);
+                        if (ob < best || (ob == best && oi < bi))
+                        {
+                            best = ob;
+                            bi   = oi;
+                        }
+                    }
+                    // distance from the position to the nearest edge of the 3 x 3 block (>= one cell), minus slack for
+                    // the rounding of the cell arithmetic and of d2
+                    const float ex = fminf(ag.pos_x - (g.x0 + static_cast<float>(ci - 1) * g.cell), (g.x0 + static_cast<float>(ci + 2) * g.cell) - ag.pos_x);
+                    const float ey = fminf(ag.pos_y - (g.y0 + static_cast<float>(cj - 1) * g.cell), (g.y0 + static_cast<float>(cj + 2) * g.cell) - ag.pos_y);
+                    const float m  = fminf(ex, ey) - 0.05F;
+                    done           = bi != 0x7FFFFFFF && m > 0.F && best < m * m;
                 }
             }
-            for (int off = 1; off < G; off <<= 1)
+            if (!done)
             {
-                const float ob = __shfl_xor(best, off, 64);
-                const int   oi = __shfl_xor(bi, off, 64);
-                if (ob < best || (ob == best && oi < bi))
+                best = 3.402823466e+38F;
+                bi   = 0x7FFFFFFF;
+                for (int i = r; i < p.P; i += G)
                 {
-                    best = ob;
-                    bi   = oi;
+                    const float dx = ag.pos_x - lds_cx[i], dy = ag.pos_y - lds_cy[i];
+                    const float d2 = dx * dx + dy * dy;
+                    if (d2 < best)
+                    {
+                        best = d2;
+                        bi   = i;
+                    }
+                }
+                for (int off = 1; off < G; off <<= 1)
+                {
+                    const float ob = __shfl_xor(best, off, 64);
+                    const int   oi = __shfl_xor(bi, off, 64);
+                    if (ob < best || (ob == best && oi < bi))
+                    {
+                        best = ob;
+                        bi   = oi;
+                    }
                 }
             }
             const int   nearest = (bi == 0x7FFFFFFF) ? 0 : bi;
