@@ -409,7 +409,11 @@ okMlpAction(const OkStepParams &p, const int a, const int rlane, const int G, Ok
     const float  xs  = ray_ok ? dist_self / 200.0F : 0.F;
     const int    own = OK_MLP_HID_PAD / kUnits; // lanes of the group that own hidden units (= min(G, 32))
     const int    ul  = rlane < own ? rlane : own - 1;
-    float        h[kUnits];
+    // Weights stream from L2 / Infinity Cache (5.3 KB per agent and step).  They are fetched sixteen rows at a time before
+    // the multiply-adds that consume them, so that a lane waits for one memory round trip per sixteen terms instead of one
+    // per term; the additions keep their order (input 0, 1, 2, ... / hidden unit 0, 1, 2, ...), hence the same bits.
+    constexpr int kAhead = 16;
+    float         h[kUnits];
 #pragma unroll
     for (int u = 0; u < kUnits; ++u)
     {
@@ -417,8 +421,17 @@ okMlpAction(const OkStepParams &p, const int a, const int rlane, const int G, Ok
         float     acc  = 0.F;
         acc            = acc + x0 * w1[0 * OK_MLP_HID_PAD + unit];
         acc            = acc + x1 * w1[1 * OK_MLP_HID_PAD + unit];
-        for (int j = 0; j < p.R; ++j)
-            acc = acc + __shfl(xs, j, G) * w1[(2 + j) * OK_MLP_HID_PAD + unit];
+        for (int j0 = 0; j0 < p.R; j0 += kAhead)
+        {
+            float w[kAhead];
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k)
+                w[k] = (j0 + k < p.R) ? w1[(2 + j0 + k) * OK_MLP_HID_PAD + unit] : 0.F;
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k)
+                if (j0 + k < p.R)
+                    acc = acc + __shfl(xs, j0 + k, G) * w[k];
+        }
         h[u] = (acc > 0.F) ? acc : 0.F;
     }
     const int kl = rlane < OK_MLP_OUT_PAD ? rlane : OK_MLP_OUT_PAD - 1;
@@ -426,11 +439,19 @@ okMlpAction(const OkStepParams &p, const int a, const int rlane, const int G, Ok
 #pragma unroll
     for (int u = 0; u < kUnits; ++u)
     {
-        for (int l = 0; l < own; ++l)
+        for (int l0 = 0; l0 < own; l0 += kAhead)
         {
-            const int   i  = l + u * own; // hidden unit index, visited in increasing order
-            const float hv = __shfl(h[u], l, G);
-            z              = z + hv * w2[i * OK_MLP_OUT_PAD + kl];
+            float w[kAhead];
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k)
+                w[k] = (l0 + k < own) ? w2[(l0 + k + u * own) * OK_MLP_OUT_PAD + kl] : 0.F;
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k)
+                if (l0 + k < own)
+                { // hidden unit index l0 + k + u * own, visited in increasing order
+                    const float hv = __shfl(h[u], l0 + k, G);
+                    z              = z + hv * w[k];
+                }
         }
     }
     float zs[OK_MLP_OUT];
