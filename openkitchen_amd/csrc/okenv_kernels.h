@@ -624,6 +624,19 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
         q_prev   = p.q_prev_idx[a];
         q_row0   = p.q_table + static_cast<size_t>(a) * (OK_Q_STATES * OK_Q_ACTIONS);
     }
+    // Q values of the agent's current state.  The table (47.8 MB at C5) lives in HBM / Infinity Cache and only this
+    // group ever touches this agent's part of it, so the row is read once per launch and then carried in registers:
+    // after a step it is either patched with the value just learned or replaced by the next state's row, which the
+    // update needs anyway.  One memory round trip per step instead of three; loads and stores stay agent-scope because
+    // lane 0 of the group writes what the others have read.
+    float qc0 = 0.F, qc1 = 0.F, qc2 = 0.F;
+    if (kPolicy == kPolicyQ)
+    {
+        const float *row = q_row0 + q_state * OK_Q_ACTIONS;
+        qc0              = __hip_atomic_load(row + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        qc1              = __hip_atomic_load(row + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        qc2              = __hip_atomic_load(row + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
 #if defined(OKENV_STAMPS)
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
@@ -643,13 +656,9 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
         if (kPolicy == kPolicyMlp)
             okPolicyAction(p, a, r, G, ag, last_dist, ray_ok);
         if (kPolicy == kPolicyQ)
-        { // QLearnAgent::updateAction (QAgent.hpp:98-119); table reads bypass L1 (lane 0 of the group rewrites rows)
-            const float *row = q_row0 + q_state * OK_Q_ACTIONS;
-            const float  q0  = __hip_atomic_load(row + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float  q1  = __hip_atomic_load(row + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float  q2  = __hip_atomic_load(row + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            q_action         = ok_q_choose_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s),
-                                                  p.q_epsilon, q0, q1, q2);
+        { // QLearnAgent::updateAction (QAgent.hpp:98-119) from the carried row of the current state
+            q_action = ok_q_choose_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s), p.q_epsilon,
+                                          qc0, qc1, qc2);
             ok_q_action_values(q_action, &ag.thr, &ag.steer);
         }
         float sr, cr;
@@ -841,12 +850,24 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
             mq                  = (n1 > mq) ? n1 : mq;
             mq                  = (n2 > mq) ? n2 : mq;
             float *cell         = q_row0 + q_state * OK_Q_ACTIONS + q_action;
-            const float old_q   = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float old_q   = (q_action == 0) ? qc0 : ((q_action == 1) ? qc1 : qc2);
             const float new_q   = ok_q_learn(old_q, mq, reward);
             if (agent_ok && r == 0)
                 __hip_atomic_store(cell, new_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the row carried into the next step: the current one with the learned value, or the next state's
+            qc0 = (q_action == 0) ? new_q : qc0;
+            qc1 = (q_action == 1) ? new_q : qc1;
+            qc2 = (q_action == 2) ? new_q : qc2;
             if (!ag.crashed)
+            {
+                if (next_state != q_state)
+                {
+                    qc0 = n0;
+                    qc1 = n1;
+                    qc2 = n2;
+                }
                 q_state = next_state;
+            }
         }
         OK_STAMP(5);
     }
