@@ -199,8 +199,9 @@ inline OkGridHost okBuildGrid(const OkSeg *segs, const size_t num_segments, floa
 //   slots[]   8 B per point.  Each cell owns a contiguous, 16-byte aligned range of slots holding, run after run,
 //             the points of the chained segments registered in it (a run of n chained segments = n + 1 points),
 //             padded to an even count with a copy of its last point.
-//   hdr[cell] 8 bytes: { first_slot | (n_slots << 20), brk } where bit j of brk is set when NO segment joins slot
-//             first_slot + j - 1 to slot first_slot + j (first point of a run, padding).  n_slots <= 32.
+//   hdr[cell] 8 bytes: { first_slot | (n_slots << 20), brk }: a break bit per slot j, set when NO segment joins slot
+//             first_slot + j - 1 to slot first_slot + j (first point of a run, padding, every j >= n_slots), stored in the
+//             point loop's accumulator order (OkCellHdr in ok_raycast.h).  n_slots <= 32.
 // Consecutive slots k, k+1 with the break bit of k+1 clear are one registered segment; because chained segments of the
 // reference's boundary polylines share end points bit for bit, a run costs one point per segment.
 struct OkPolyImage
@@ -238,7 +239,7 @@ inline OkPolyImage okBuildPolyImage(const OkSeg *segs, const size_t num_segments
     const size_t           ncell = grid.numCells();
     std::vector<OkPoint>   slots;
     std::vector<uint8_t>   brk; // one byte per slot while building
-    std::vector<OkCellHdr> hdr(ncell, OkCellHdr{0U, 1U});
+    std::vector<OkCellHdr> hdr(ncell, OkCellHdr{0U, ~0U});
     bool                   encodable = true;
     std::vector<OkPoint>   cs; // the cell's slots before chunking
     std::vector<uint8_t>   cb;
@@ -312,7 +313,15 @@ inline OkPolyImage okBuildPolyImage(const OkSeg *segs, const size_t num_segments
             if (first_slot > OKPOLY_IDX_MASK)
                 encodable = false;
             const bool      more = pos < cs.size();
-            const OkCellHdr hv{first_slot | (count << OKPOLY_IDX_BITS) | ((more ? 1U : 0U) << (OKPOLY_IDX_BITS + 6)), bits | 1U};
+            // break bits in the point loop's accumulator order (ok_raycast.h): the loop evaluates n8 = count rounded up to 8
+            // slots and shifts one bit in per slot, so slot j ends up at bit n8 - 1 - j; everything that is not a pair of
+            // chained points -- slot 0, run starts, padding, the slots from `count` on, the bits from n8 on -- is a break
+            const uint32_t n8  = (count + 7U) & ~7U;
+            uint32_t       rev = n8 < 32U ? (~0U << n8) : 0U;
+            for (uint32_t j = 0; j < n8; ++j)
+                if (j >= count || j == 0U || ((bits >> j) & 1U) != 0U)
+                    rev |= 1U << (n8 - 1U - j);
+            const OkCellHdr hv{first_slot | (count << OKPOLY_IDX_BITS) | ((more ? 1U : 0U) << (OKPOLY_IDX_BITS + 6)), rev};
             if (hdr_in_slot < 0)
                 hdr[c] = hv;
             else
@@ -330,10 +339,11 @@ inline OkPolyImage okBuildPolyImage(const OkSeg *segs, const size_t num_segments
         if (!encodable)
             break;
     }
-    slots.push_back({0.F, 0.F}); // the exact test of slot k reads k+1; keep the last read in bounds
-    slots.push_back({0.F, 0.F});
-    brk.push_back(1);
-    brk.push_back(1);
+    for (int pad = 0; pad < 16; ++pad)
+    { // the exact test of slot k reads k+1 and the point loop reads up to six slots past a chunk: keep those reads in bounds
+        slots.push_back({0.F, 0.F});
+        brk.push_back(1);
+    }
     img.ok        = encodable;
     img.num_slots = static_cast<uint32_t>(slots.size());
     if (!encodable)
@@ -344,11 +354,17 @@ inline OkPolyImage okBuildPolyImage(const OkSeg *segs, const size_t num_segments
     img.bytes.assign(slot_b + hdr_b, 0);
     std::memcpy(img.bytes.data(), slots.data(), slots.size() * sizeof(OkPoint));
     std::memcpy(img.bytes.data() + img.off_hdr, hdr.data(), hdr.size() * sizeof(OkCellHdr));
-    // side tolerance (ok_raycast.h): any point met by a walk lies within A = range + two cell diagonals + the
-    // longest segment + margin of the ray origin; rounding differences between the skip rule's sides and the
-    // reference's num_s / denom are below ~4 * 2^-23 * 4A; take 2^-17 * A (16x that).
+    // side tolerance (ok_raycast.h).  Two parts:
+    //  * any point met by a walk lies within A = range + two cell diagonals + the longest segment + margin of the ray
+    //    origin; rounding differences between a point's true side and the reference's num_s / (num_s - denom) are below
+    //    ~4 * 2^-23 * 4A = 2^-19 A; take 2^-17 * A (4x that);
+    //  * the walk evaluates side(p) = p.x * dy - p.y * dx - c, c = o.x * dy - o.y * dx, with four roundings (o.y * dx, the
+    //    FMA giving c, the two FMAs of a point) of intermediates no larger than 4M, M = the largest coordinate magnitude
+    //    involved: the grid box's corners, and an origin at most one sensor range outside it (a walk only happens when the
+    //    ray enters the box within the range).  That is <= 10 * 2^-24 * M away from the true side; take 2^-19 * M (3x that).
     const double A = 200.0 + 2.0 * 1.4143 * grid.g.cell + max_len + 2.0 * grid.margin;
-    img.side_tol   = static_cast<float>(std::ldexp(A, -17));
+    const double M = std::fmax(std::fmax(std::fabs(grid.g.x0), std::fabs(grid.g.x1)), std::fmax(std::fabs(grid.g.y0), std::fabs(grid.g.y1))) + 201.0;
+    img.side_tol   = static_cast<float>(std::ldexp(A, -17) + std::ldexp(M, -19));
     return img;
 }
 

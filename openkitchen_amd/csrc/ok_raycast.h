@@ -87,7 +87,9 @@ struct OkGridView32
 struct OkCellHdr
 {
     uint32_t w0;  // first_slot (20 bits) | n_slots << 20 (6 bits, even, <= 32) | has_next << 26
-    uint32_t brk; // bit j set: NO segment joins slots first_slot + j - 1 and first_slot + j (run start, padding); bit 0 is set
+    uint32_t brk; // break bits, in the point loop's accumulator order: with n8 = n_slots rounded up to 8, bit (n8 - 1 - j) is
+                  // set when NO segment joins slots first_slot + j - 1 and first_slot + j (j = 0, run starts, padding, every
+                  // j >= n_slots); the bits from n8 on are set too
 };
 // A cell with more than 32 slots continues in further chunks: when has_next is set, the next chunk's header occupies
 // the slot right after this chunk's slots (slot index first_slot + n_slots, 8 bytes, followed by one unused slot).  A
@@ -294,6 +296,100 @@ OKRC_HD bool ok_same_side(const float s0, const float s1, const float tol)
 #endif
 }
 
+// Bit pattern helpers (plain C++: memcpy compiles to nothing on both sides).
+OKRC_HD uint32_t okBits(const float x)
+{
+    uint32_t u;
+    __builtin_memcpy(&u, &x, 4);
+    return u;
+}
+OKRC_HD float okFromBits(const uint32_t u)
+{
+    float x;
+    __builtin_memcpy(&x, &u, 4);
+    return x;
+}
+
+OKRC_HD int32_t okMin3i(const int32_t a, const int32_t b, const int32_t c)
+{
+    const int32_t m = a < b ? a : b;
+    return m < c ? m : c;
+}
+OKRC_HD int32_t okMax3i(const int32_t a, const int32_t b, const int32_t c)
+{
+    const int32_t m = a > b ? a : b;
+    return m > c ? m : c;
+}
+
+// The reference's test (ok_ray_segment) against the current first hit `min_t`, with the two IEEE divisions taken out of
+// the common path: returns the updated first-hit parameter, bit for bit what
+//     float t; return ok_ray_segment(ox, oy, rdx, rdy, a.x, a.y, b.x, b.y, min_t, t) ? t : min_t;
+// returns.  num_t, num_s and denom are computed exactly as there.  When all three lie in a "regular" range
+// (|denom| in [1e-8, 1e10), |num| in [1e-20, 1e10)) every quotient num/denom is a normal number of magnitude >= 1e-30
+// whose sign is the product of the signs, so with the numerators' signs folded by denom's (fs, ft):
+//     s >= 0  <=>  fs > 0                       s <= 1  <=>  fs <= |denom|
+//         (a correctly rounded quotient of two floats exceeds 1 whenever the numerator exceeds the denominator:
+//          the smallest such quotient is 1 + 1/(2^24 - 1) > 1 + 2^-24, which rounds up, never to 1)
+//     t >= 0  <=>  ft > 0
+//     t <= min_t  =>  ft <= (min_t * 1.00001) * |denom|      (rounding of t and of the products is < 4e-7 relative)
+// The last line is only a filter: survivors compute t = num_t / denom (IEEE) and compare it with min_t exactly as the
+// reference does, so it merely has to let every acceptable candidate through.  Anything irregular (zero or tiny
+// numerators, huge or non-finite values) takes the reference's own sequence of two divisions.
+//
+// The range tests run on the bit patterns: non-negative floats order like their bits read as integers, NaNs and
+// infinities sort above every finite value, and "0 < x <= y" for y >= 0 is the single unsigned comparison
+// bits(x) - 1 < bits(y) (x = +0 wraps to the top, negative x and NaNs have bits above every non-negative finite y).
+OKRC_HD float ok_first_hit_update(const float   ox,
+                                  const float   oy,
+                                  const float   rdx,
+                                  const float   rdy,
+                                  const OkPoint a,
+                                  const OkPoint b,
+                                  const float   min_t)
+{
+    constexpr int32_t kBitsLo  = 0x1E3CE508; // 1e-20f
+    constexpr int32_t kBitsHi  = 0x501502F9; // 1e10f
+    constexpr int32_t kBitsEps = 0x322BCC77; // 1e-8f = OK_PARALLEL_EPS
+    const float    sdx   = b.x - a.x;
+    const float    sdy   = b.y - a.y;
+    const float    denom = rdx * sdy - rdy * sdx;
+    const float    ex    = a.x - ox;
+    const float    ey    = a.y - oy;
+    const float    num_t = ex * sdy - ey * sdx;
+    const float    num_s = ex * rdy - ey * rdx;
+    const uint32_t sg    = okBits(denom) & 0x80000000U;
+    const uint32_t bd    = okBits(denom) ^ sg;       // bits of |denom|
+    const uint32_t bfs   = okBits(num_s) ^ sg;       // bits of fs = num_s with denom's sign folded in
+    const uint32_t bft   = okBits(num_t) ^ sg;
+    const int32_t  bas   = static_cast<int32_t>(bfs & 0x7FFFFFFFU); // bits of |num_s|, |num_t|: non-negative as integers
+    const int32_t  bat   = static_cast<int32_t>(bft & 0x7FFFFFFFU);
+    // regular <=> |num_s|, |num_t| in [1e-20, 1e10) and |denom| in [1e-8, 1e10); |denom|'s lower bound is moved onto the
+    // numerators' by the (signed) offset, so one three-way minimum and one three-way maximum decide it
+    const int32_t lo = okMin3i(bas, bat, static_cast<int32_t>(bd) - (kBitsEps - kBitsLo));
+    const int32_t hi = okMax3i(bas, bat, static_cast<int32_t>(bd));
+    float         result = min_t;
+    if (lo >= kBitsLo && hi < kBitsHi)
+    {
+        const float lim = (min_t * 1.00001F) * okFromBits(bd);
+        if ((bfs - 1U < bd) && (bft - 1U < okBits(lim)))
+        { // s is in [0, 1]; t is positive and not clearly beyond min_t
+            const float t = num_t / denom;
+            result        = (t <= min_t) ? t : min_t;
+        }
+    }
+    else if (!(okFromBits(bd) < OK_PARALLEL_EPS))
+    { // the reference's own sequence (CollisionChecker.cu:23-33)
+        const float t = num_t / denom;
+        if ((t >= 0.0F) && (t <= min_t))
+        {
+            const float sq = num_s / denom;
+            if ((sq >= 0.0F) && (sq <= 1.0F))
+                result = t;
+        }
+    }
+    return result;
+}
+
 // exact test of the registered segment (slot k, slot k+1); returns the updated first-hit parameter
 OKRC_HD float okExactSlot(const OkPolyView &v,
                           const uint32_t    k,
@@ -305,8 +401,12 @@ OKRC_HD float okExactSlot(const OkPolyView &v,
 {
     const OkPoint a = v.slots[k];
     const OkPoint b = v.slots[k + 1];
-    float         t;
+#if defined(OKRC_OLD_EXACT) // ablation: the reference's sequence on every survivor
+    float t;
     return ok_ray_segment(ox, oy, rdx, rdy, a.x, a.y, b.x, b.y, min_t, t) ? t : min_t;
+#else
+    return ok_first_hit_update(ox, oy, rdx, rdy, a, b, min_t);
+#endif
 }
 
 OKRC_HD uint32_t okCountTrailingZeros(const uint32_t x)
@@ -323,11 +423,69 @@ struct OkIntervalResult
                       // the sensor range / left the grid
 };
 
+struct alignas(16) OkVec4 // 16-byte aligned load unit (ds_read_b128): two consecutive slots
+{
+    float x, y, z, w;
+};
+
+// median of three; one v_med3_f32 on the GPU
+OKRC_HD float okMed3(const float a, const float b, const float c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(a, b, c);
+#else
+    const float lo = __builtin_fminf(a, b), hi = __builtin_fmaxf(a, b);
+    return __builtin_fmaxf(lo, __builtin_fminf(hi, c));
+#endif
+}
+
+// (acc << 1) | sign bit of d; one v_alignbit_b32 on the GPU
+OKRC_HD uint32_t okShiftInSign(const uint32_t acc, const float d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(acc, okBits(d), 31U);
+#else
+    return (acc << 1) | (okBits(d) >> 31);
+#endif
+}
+
+// Diagnostic build only (-DOKENV_STAMPS): shader-clock stamps inside the walk.  prof[0] walk set-up, [1] cell entry
+// (header decode), [2] point loop, [3] exact loop, [4] leaving the cell.
+#if defined(OKENV_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define OKRC_PROF_BEGIN() unsigned long long prof_last_ = __builtin_amdgcn_s_memtime()
+#define OKRC_PROF(i)                                                                                                   \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (prof != nullptr)                                                                                           \
+        {                                                                                                              \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                              \
+            prof[i] += now_ - prof_last_;                                                                              \
+            prof_last_ = now_;                                                                                         \
+        }                                                                                                              \
+    } while (0)
+#else
+#define OKRC_PROF_BEGIN() ((void)0)
+#define OKRC_PROF(i) ((void)0)
+#endif
+
 // Walks the cells the ray crosses for parameters in [t_a, t_b] and reports the first hit among the segments
 // registered there.  The whole ray is the interval [0, +inf).  Splitting a ray into intervals and taking the min
 // of their min_t gives the same bits as one walk: every cell overlapping [t_a, t_b] is processed, a valid t found
 // in ANY cell is a valid t of the ray (the exact test does not depend on the cell it was found in), and a walk
 // only stops early on a hit that lies inside the part it has covered.
+//
+// Written for the way a gfx950 wave executes it: all 64 lanes run the loops in lock step, a wave is paced by its own
+// instruction stream (one instruction per ~4 cycles) and by exposed LDS round trips (~150 cycles), and idle lanes are
+// free.  Hence:
+//   set-up      branch free (slab clip, start cell, DDA increments); the walk keeps a linear cell index and counts the
+//               steps left to the grid's border, so a step is an add, not an (ix, iy) -> index multiplication
+//   cell loop   the next cell's header is requested before the current cell is processed
+//   point loop  eight slots per pass (four ds_read_b128), whatever the chunk's length: what is read past the chunk is
+//               masked by the header's break bits.  A point's side is two FMAs: side(p) = p.x * dy - p.y * dx - c with
+//               c = o.x * dy - o.y * dx formed once per walk (rounding analysis at side_tol in ok_grid.h); the skip
+//               decision of a pair is the sign of tol - |med3(side, side', 0)|, shifted into a bit accumulator
+//               (v_med3, v_sub, v_alignbit: no compare-to-mask round trip)
+//   exact loop  pairs whose accumulator bit AND break bit are clear, ok_first_hit_update
 template <bool kCount>
 OKRC_HD OkIntervalResult ok_cast_poly_interval(const OkPolyView &v,
                                                const float       ox,
@@ -338,74 +496,162 @@ OKRC_HD OkIntervalResult ok_cast_poly_interval(const OkPolyView &v,
                                                const float       t_b,
                                                uint32_t         *tests,
                                                uint32_t         *cells,
-                                               uint32_t         *points)
+                                               uint32_t         *points,
+                                               unsigned long long *prof = nullptr)
 {
     const OkGridGeom &g = v.g;
-    OkWalk            w;
-    if (!w.init(g, ox, oy, rdx, rdy, t_a))
+    OKRC_PROF_BEGIN();
+    // ---- set-up: slab clip of [t_a, range] against the grid box (same arithmetic as OkWalk::init) ----
+    const bool  par_x  = __builtin_fabsf(rdx) < 1e-30F;
+    const bool  par_y  = __builtin_fabsf(rdy) < 1e-30F;
+    const float inv_dx = par_x ? 0.0F : okRcpApprox(rdx);
+    const float inv_dy = par_y ? 0.0F : okRcpApprox(rdy);
+    const float tax = (g.x0 - ox) * inv_dx, tbx = (g.x1 - ox) * inv_dx;
+    const float tay = (g.y0 - oy) * inv_dy, tby = (g.y1 - oy) * inv_dy;
+    float       t_in  = t_a;
+    float       t_out = OK_SENSOR_RANGE;
+    t_in              = par_x ? t_in : __builtin_fmaxf(t_in, __builtin_fminf(tax, tbx));
+    t_out             = par_x ? t_out : __builtin_fminf(t_out, __builtin_fmaxf(tax, tbx));
+    t_in              = par_y ? t_in : __builtin_fmaxf(t_in, __builtin_fminf(tay, tby));
+    t_out             = par_y ? t_out : __builtin_fminf(t_out, __builtin_fmaxf(tay, tby));
+    const bool in_x   = !par_x || (ox >= g.x0 && ox <= g.x1);
+    const bool in_y   = !par_y || (oy >= g.y0 && oy <= g.y1);
+    if (!(in_x && in_y && (t_in <= t_out))) // the interval misses the grid box (also rejects NaN poses)
         return {OK_SENSOR_RANGE, OK_SENSOR_RANGE, true};
-    const float tol   = v.side_tol;
-    float       min_t = OK_SENSOR_RANGE;
-    OkCellHdr   h     = v.hdr[w.iy * g.nx + w.ix];
-    // The walk visits at most nx + ny cells; the explicit bound makes termination unconditional.
-    for (int guard = g.nx + g.ny + 2; guard > 0; --guard)
-    {
-        // header of the cell the walk would enter next (clamped; unused if the walk ends first)
-        const bool go_x = w.tmax_x < w.tmax_y;
-        int        nx_i = w.ix + (go_x ? w.step_x : 0);
-        int        ny_i = w.iy + (go_x ? 0 : w.step_y);
-        nx_i            = nx_i < 0 ? 0 : (nx_i >= g.nx ? g.nx - 1 : nx_i);
-        ny_i            = ny_i < 0 ? 0 : (ny_i >= g.ny ? g.ny - 1 : ny_i);
-        const OkCellHdr h_next = v.hdr[ny_i * g.nx + nx_i];
+    const float px = ox + t_in * rdx;
+    const float py = oy + t_in * rdy;
+    int         ix = (int)__builtin_floorf((px - g.x0) * g.inv_cell);
+    int         iy = (int)__builtin_floorf((py - g.y0) * g.inv_cell);
+    ix             = ix < 0 ? 0 : (ix >= g.nx ? g.nx - 1 : ix);
+    iy             = iy < 0 ? 0 : (iy >= g.ny ? g.ny - 1 : iy);
+    const bool  fwd_x = rdx >= 0.0F, fwd_y = rdy >= 0.0F;
+    const float bx    = g.x0 + (float)(ix + (fwd_x ? 1 : 0)) * g.cell;
+    const float by    = g.y0 + (float)(iy + (fwd_y ? 1 : 0)) * g.cell;
+    float       tmax_x = par_x ? OKRC_INF : (bx - ox) * inv_dx;
+    float       tmax_y = par_y ? OKRC_INF : (by - oy) * inv_dy;
+    const float tdel_x = par_x ? OKRC_INF : g.cell * __builtin_fabsf(inv_dx);
+    const float tdel_y = par_y ? OKRC_INF : g.cell * __builtin_fabsf(inv_dy);
+    // linear cell index, its increments, and the steps left before the walk leaves the grid on either axis
+    int       cell   = iy * g.nx + ix;
+    const int lin_x  = fwd_x ? 1 : -1;
+    const int lin_y  = fwd_y ? g.nx : -g.nx;
+    int       left_x = fwd_x ? g.nx - 1 - ix : ix;
+    int       left_y = fwd_y ? g.ny - 1 - iy : iy;
+    const int last_cell = g.nx * g.ny - 1;
 
+    const float tol    = v.side_tol;
+    const float c_ray  = __builtin_fmaf(ox, rdy, -(oy * rdx)); // side(p) = p.x * dy - p.y * dx - c_ray
+    const float neg_dx = -rdx;
+    float       min_t  = OK_SENSOR_RANGE;
+
+    // What leaving the current cell will mean is known when the cell is entered, except for hits found inside it:
+    //   t_exit             parameter at which the ray leaves the cell
+    //   cell_n, tnx, tny   the next cell (index clamped into the grid) and the DDA state after the step
+    //   h_next             its header, requested now so that the LDS round trip overlaps the cell's own work
+    //   leave              0 go on | 1 conclusive: range or grid box ends inside this cell (or, set later, a hit inside the covered
+    //                      part) | 2 the interval's end t_b is reached, not conclusive | 3 conclusive: the walk leaves the grid
+    // Every loop-carried quantity is a plain register value (no lane masks carried around the loop).
+    float     t_exit, tnx, tny;
+    int       cell_n, leave;
+    OkCellHdr h_next;
+#define OKRC_ENTER_CELL()                                                                                              \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        const bool go_x = tmax_x < tmax_y;                                                                             \
+        t_exit          = __builtin_fminf(tmax_x, tmax_y);                                                             \
+        tnx             = go_x ? tmax_x + tdel_x : tmax_x;                                                             \
+        tny             = go_x ? tmax_y : tmax_y + tdel_y;                                                             \
+        left_x -= go_x ? 1 : 0;                                                                                        \
+        left_y -= go_x ? 0 : 1;                                                                                        \
+        cell_n = cell + (go_x ? lin_x : lin_y);                                                                        \
+        cell_n = cell_n < 0 ? 0 : (cell_n > last_cell ? last_cell : cell_n);                                           \
+        h_next = v.hdr[cell_n];                                                                                        \
+        leave  = (left_x | left_y) >= 0 ? 0 : 3;                                                                       \
+        leave  = (t_exit >= t_b) ? 2 : leave;                                                                          \
+        leave  = (t_out <= t_exit) ? 1 : leave;                                                                        \
+    } while (0)
+
+    OkCellHdr hc = v.hdr[cell];
+    OKRC_ENTER_CELL();
+    if (kCount)
+        *cells += 1;
+    OKRC_PROF(0);
+    // One pass per chunk of <= 32 slots (almost every cell is a single chunk; a cell's chain of chunks is finite by
+    // construction of the image).  The walk visits at most nx + ny cells: the explicit bound on cell steps makes
+    // termination unconditional.
+    int guard = g.nx + g.ny + 2;
+    while (true)
+    {
+        const uint32_t k0 = hc.w0 & OKPOLY_IDX_MASK;
+        const uint32_t n  = (hc.w0 >> OKPOLY_IDX_BITS) & OKPOLY_N_MASK;
+        if (kCount)
+            *points += n;
+        // Point loop.  After it, bit (n8 - 1 - j) of `skip` tells that the pair (slot k0+j-1, slot k0+j) lies clearly on one
+        // side of the ray (n8 = n rounded up to 8); the header's break bits use the same positions.
+        uint32_t skip = 0U;
+        float    sp   = 0.F;
+        OKRC_PROF(1);
+        for (uint32_t i = 0; i < n; i += 8)
+        {
+            const OkVec4 *q  = reinterpret_cast<const OkVec4 *>(v.slots + k0 + i); // k0 + i is even, the slot array 16-byte aligned
+            const OkVec4  q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const float   s0 = __builtin_fmaf(q0.x, rdy, __builtin_fmaf(q0.y, neg_dx, -c_ray));
+            const float   s1 = __builtin_fmaf(q0.z, rdy, __builtin_fmaf(q0.w, neg_dx, -c_ray));
+            const float   s2 = __builtin_fmaf(q1.x, rdy, __builtin_fmaf(q1.y, neg_dx, -c_ray));
+            const float   s3 = __builtin_fmaf(q1.z, rdy, __builtin_fmaf(q1.w, neg_dx, -c_ray));
+            const float   s4 = __builtin_fmaf(q2.x, rdy, __builtin_fmaf(q2.y, neg_dx, -c_ray));
+            const float   s5 = __builtin_fmaf(q2.z, rdy, __builtin_fmaf(q2.w, neg_dx, -c_ray));
+            const float   s6 = __builtin_fmaf(q3.x, rdy, __builtin_fmaf(q3.y, neg_dx, -c_ray));
+            const float   s7 = __builtin_fmaf(q3.z, rdy, __builtin_fmaf(q3.w, neg_dx, -c_ray));
+            skip             = okShiftInSign(skip, tol - __builtin_fabsf(okMed3(sp, s0, 0.F)));
+            skip             = okShiftInSign(skip, tol - __builtin_fabsf(okMed3(s0, s1, 0.F)));
+            skip             = okShiftInSign(skip, tol - __builtin_fabsf(okMed3(s1, s2, 0.F)));
+            skip             = okShiftInSign(skip, tol - __builtin_fabsf(okMed3(s2, s3, 0.F)));
+            skip             = okShiftInSign(skip, tol - __builtin_fabsf(okMed3(s3, s4, 0.F)));
+            skip             = okShiftInSign(skip, tol - __builtin_fabsf(okMed3(s4, s5, 0.F)));
+            skip             = okShiftInSign(skip, tol - __builtin_fabsf(okMed3(s5, s6, 0.F)));
+            skip             = okShiftInSign(skip, tol - __builtin_fabsf(okMed3(s6, s7, 0.F)));
+            sp               = s7;
+        }
+        // Exact tests of the surviving segments, all lanes of a wave together: the long test stays out of the point
+        // loop, and a wave runs it max-over-lanes(survivors) times per chunk (typically 2: the inner and the outer
+        // boundary).
+        uint32_t       cand = ~(skip | hc.brk);
+        const uint32_t top  = k0 + ((n + 7U) & ~7U) - 2U; // bit b <-> pair (slot top - b, slot top - b + 1)
+        OKRC_PROF(2);
+        while (cand != 0U)
+        { // highest bit first = ascending slots, the order of the reference's sweep inside a run (it decides which of
+          // two hits at t = +0 / -0 is kept)
+            const uint32_t z = static_cast<uint32_t>(__builtin_clz(cand));
+            cand &= ~(0x80000000U >> z);
+            if (kCount)
+                *tests += 1;
+            min_t = okExactSlot(v, top - (31U - z), ox, oy, rdx, rdy, min_t);
+        }
+        OKRC_PROF(3);
+        if (((hc.w0 >> (OKPOLY_IDX_BITS + 6)) & 1U) != 0U)
+        { // the cell continues in another chunk: its header sits right behind this chunk's slots
+            hc = *reinterpret_cast<const OkCellHdr *>(&v.slots[k0 + n]);
+            continue;
+        }
+        // leave the cell
+        leave = (min_t <= t_exit) ? 1 : leave; // first hit inside the covered part
+        if (leave != 0 || --guard <= 0)
+            break;
+        cell   = cell_n;
+        tmax_x = tnx;
+        tmax_y = tny;
+        hc     = h_next;
+        OKRC_ENTER_CELL();
         if (kCount)
             *cells += 1;
-        OkCellHdr hc = h;
-        while (true) // one pass per chunk of <= 32 slots; almost every cell is a single chunk
-        {
-            const uint32_t k0 = hc.w0 & OKPOLY_IDX_MASK;
-            const uint32_t n  = (hc.w0 >> OKPOLY_IDX_BITS) & OKPOLY_N_MASK;
-            if (kCount)
-                *points += n;
-            // Point loop: branch-free.  Bit j of `surv` = the pair (slot k0+j-1, slot k0+j) survived the side rule.
-            uint32_t surv   = 0U;
-            float    s_prev = 0.F;
-            for (uint32_t i = 0; i < n; i += 2)
-            {
-                const OkPointPair pp = *reinterpret_cast<const OkPointPair *>(&v.slots[k0 + i]);
-                const float       sa = ok_side(pp.a, ox, oy, rdx, rdy);
-                const float       sb = ok_side(pp.b, ox, oy, rdx, rdy);
-                s_prev               = (i == 0U) ? sa : s_prev; // the chunk's first slot has no predecessor (brk bit 0)
-                const uint32_t m     = (ok_same_side(s_prev, sa, tol) ? 0U : 1U) | (ok_same_side(sa, sb, tol) ? 0U : 2U);
-                surv |= m << i;
-                s_prev = sb;
-            }
-            // Exact tests of the surviving segments, all lanes of a wave together: the long, division-heavy test stays
-            // out of the point loop, and a wave runs it max-over-lanes(survivors) times per cell (typically 2: the inner
-            // and the outer boundary).  Order does not matter: min is order independent.
-            surv &= ~hc.brk;
-            while (surv != 0U)
-            {
-                const uint32_t j = okCountTrailingZeros(surv);
-                surv &= surv - 1U;
-                if (kCount)
-                    *tests += 1;
-                min_t = okExactSlot(v, k0 + j - 1U, ox, oy, rdx, rdy, min_t);
-            }
-            if (((hc.w0 >> (OKPOLY_IDX_BITS + 6)) & 1U) == 0U)
-                break;
-            hc = *reinterpret_cast<const OkCellHdr *>(&v.slots[k0 + n]);
-        }
-        const float t_exit = w.exitT();
-        if (__builtin_fminf(min_t, w.t_out) <= t_exit)
-            return {min_t, t_exit, true};
-        if (t_exit >= t_b)
-            return {min_t, t_exit, false};
-        if (!w.advance(g))
-            return {min_t, OK_SENSOR_RANGE, true};
-        h = h_next;
+        OKRC_PROF(4);
     }
-    return {min_t, OK_SENSOR_RANGE, true};
+#undef OKRC_ENTER_CELL
+    // leave == 0 only if the guard ran out, which cannot happen; treat it like leaving the grid
+    const float t_reached  = (leave == 1 || leave == 2) ? t_exit : OK_SENSOR_RANGE;
+    const bool  conclusive = leave != 2;
+    return {min_t, t_reached, conclusive};
 }
 
 // First-hit parameter of one whole ray, compact form.

@@ -251,6 +251,13 @@ size_t qLdsBytes(const okenv *h)
     return 8U * static_cast<size_t>(h->P) + 2U * (cells + 1U) + 2U * static_cast<size_t>(h->P) + 16U;
 }
 
+// LDS every cooperative launch needs behind the image (the per-SIMD progress words)
+constexpr size_t kCoopLdsExtra = 16U;
+size_t coopLdsBytes(const okenv *h)
+{
+    return h->image_bytes + kCoopLdsExtra;
+}
+
 // Buckets the centre-line points by the cells of the raycast grid (CSR, indices ascending inside a cell) and uploads
 // them; a centre line with more than 65535 points keeps the full scan.
 int buildCenterlineBuckets(okenv *h)
@@ -324,7 +331,7 @@ int launchStep(okenv *h, const OkStepParams &p)
     case kGridLds:
         if (h->coop)
         {
-            const size_t   lds = h->image_bytes;
+            const size_t   lds = coopLdsBytes(h);
             const uint32_t off = static_cast<uint32_t>(h->image_bytes);
             if (p.action_source == kActionsQLearning)
                 hipLaunchKernelGGL(okStepCoopKernel<kPolicyQ>, grid, block, lds + qLdsBytes(h), h->stream, p, off,
@@ -434,7 +441,11 @@ extern "C"
         // ---- grid ------------------------------------------------------------------------------------
         const OkSeg *segs = reinterpret_cast<const OkSeg *>(segments_xyxy);
         bool         fits = false;
-        h->grid = okBuildGridAuto(segs, static_cast<size_t>(num_segments), grid_cell, kLdsBudget - kLdsReserve, &fits, &h->poly);
+        // cell edge: 24 px when a wave holds one agent (all 64 rays leave one origin), 20 px when it holds several (measured:
+        // Silverstone / Spa x 64 rays 4 % faster at 24, Monza x 32 rays 6 % faster at 20)
+        const float cell_default = (h->G == 64 && h->rays_per_lane == 1 && num_rays > 32) ? 24.F : OKGRID_DEFAULT_CELL;
+        h->grid = okBuildGridAuto(segs, static_cast<size_t>(num_segments), grid_cell > 0.F ? grid_cell : cell_default, kLdsBudget - kLdsReserve,
+                                  &fits, &h->poly);
         if (flags & OKENV_FLAG_BRUTE_FORCE)
             h->grid_mode = kGridBrute;
         else if (!fits || (flags & OKENV_FLAG_FORCE_GLOBAL_GRID))
@@ -456,7 +467,7 @@ extern "C"
             h->d_image = dimg;
             OK_HIP(nullptr, hipMemcpyAsync(dimg, img.data(), h->image_bytes, hipMemcpyHostToDevice, h->stream));
             OK_HIP(nullptr, hipStreamSynchronize(h->stream));
-            const int lds_plain = static_cast<int>(h->image_bytes), lds_coop = lds_plain;
+            const int lds_plain = static_cast<int>(h->image_bytes), lds_coop = static_cast<int>(coopLdsBytes(h));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepKernel<kGridLds, kPolicyNone>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_plain));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepKernel<kGridLds, kPolicyMlp>),
@@ -473,7 +484,7 @@ extern "C"
 #if defined(OKENV_STAMPS)
         if (h->grid_mode == kGridLds)
         { // diagnostic build: d_refs32 doubles as the stamp buffer (6 x u64 per wave)
-            if ((rc = devAlloc(h, &h->d_refs32, static_cast<size_t>(num_agents) * 64U / 64U * 12U + 1024U)) != OKENV_OK)
+            if ((rc = devAlloc(h, &h->d_refs32, static_cast<size_t>(num_agents) * 32U + 1024U)) != OKENV_OK)
                 return fail(nullptr, rc, h->last_error);
         }
 #endif
@@ -1307,7 +1318,7 @@ extern "C"
             return fail(h, OKENV_ERR_STATE, "okenv_rollout_q: call okenv_q_create first");
         if (n_steps == 0)
             return OKENV_OK;
-        if (h->image_bytes + qLdsBytes(h) > kLdsBudget)
+        if (coopLdsBytes(h) + qLdsBytes(h) > kLdsBudget)
             return fail(h, OKENV_ERR_STATE, "okenv_rollout_q: track image + centre line do not fit the CU's LDS");
         OK_HIP(h, hipSetDevice(h->device));
         const int brc = buildCenterlineBuckets(h);
@@ -1550,7 +1561,7 @@ extern "C"
     __attribute__((visibility("default"))) int okenv_debug_stamps(okenv_t h, unsigned long long *out, int waves)
     {
         OK_HIP(h, hipStreamSynchronize(h->stream));
-        OK_HIP(h, hipMemcpy(out, h->d_refs32, sizeof(unsigned long long) * 6U * waves, hipMemcpyDeviceToHost));
+        OK_HIP(h, hipMemcpy(out, h->d_refs32, sizeof(unsigned long long) * 16U * waves, hipMemcpyDeviceToHost));
         return OKENV_OK;
     }
 #endif

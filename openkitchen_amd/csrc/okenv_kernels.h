@@ -117,14 +117,66 @@ enum OkGridMode : int
     kGridBrute  = 2, // no grid: sweep all segments (the reference kernel's algorithm; testing/ablation)
 };
 
+// Cross-lane moves that stay in the VALU (no LDS round trip): DPP inside a row of 16 lanes, the gfx950 lane-swap
+// instructions across rows.
+template <int kCtrl>
+__device__ __forceinline__ float okDppMove(const float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), kCtrl, 0xF, 0xF, true));
+}
+constexpr int kDppXor1       = 0xB1;  // quad_perm [1,0,3,2]
+constexpr int kDppXor2       = 0x4E;  // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141; // lane i <- lane 7 - i of its group of 8
+constexpr int kDppMirror     = 0x140; // lane i <- lane 15 - i of its row
+
 // min over the G lanes that belong to one agent; every lane of the group receives the result.
 // (a < b ? a : b) keeps the sequential loop's "NaN never wins" behaviour (CollisionChecker.cu:161-164).
+// The butterfly's partners are lane ^ 1, lane ^ 2, then the mirrored lane of the group of 8 / of the row (once the
+// groups of 4 / 8 agree, the mirrored lane holds what lane ^ 4 / lane ^ 8 holds), then the other row / other half of
+// the wave through v_permlane16_swap / v_permlane32_swap: six VALU steps, no ds_bpermute.
 __device__ __forceinline__ float okGroupMin(float v, const int G)
 {
+#if defined(OKENV_SHUFFLE_GROUPMIN) // ablation: the ds_bpermute butterfly
     for (int off = 1; off < G; off <<= 1)
     {
         const float o = __shfl_xor(v, off, 64);
         v             = (o < v) ? o : v;
+    }
+    return v;
+#endif
+    float o;
+    if (G > 1)
+    {
+        o = okDppMove<kDppXor1>(v);
+        v = (o < v) ? o : v;
+    }
+    if (G > 2)
+    {
+        o = okDppMove<kDppXor2>(v);
+        v = (o < v) ? o : v;
+    }
+    if (G > 4)
+    {
+        o = okDppMove<kDppHalfMirror>(v);
+        v = (o < v) ? o : v;
+    }
+    if (G > 8)
+    {
+        o = okDppMove<kDppMirror>(v);
+        v = (o < v) ? o : v;
+    }
+    // (inline asm: with the builtin, hipcc 7.2 drops the min that follows the swap -- it treats the two results as equal)
+    if (G > 16)
+    {
+        float a = v, b = v;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+        v = (a < b) ? a : b;
+    }
+    if (G > 32)
+    {
+        float a = v, b = v;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+        v = (a < b) ? a : b;
     }
     return v;
 }
@@ -269,7 +321,8 @@ __device__ __forceinline__ void okAgentPreStep(const OkStepParams &p,
                                                float              &cs,
                                                const float         ray_deg = 0.F,
                                                float              *ray_sn  = nullptr,
-                                               float              *ray_cs  = nullptr)
+                                               float              *ray_cs  = nullptr,
+                                               const ok_random_action *drawn = nullptr)
 {
     if ((p.reset_flags & kAutoResetOn) != 0U && r.crashed)
     {
@@ -289,8 +342,9 @@ __device__ __forceinline__ void okAgentPreStep(const OkStepParams &p,
     }
     if (p.action_source == kActionsPhiloxReset)
     {
+        // the caller may have drawn this step's action already (okStepCoopKernel draws a block of steps at a time)
         const ok_random_action ra =
-            ok_draw_random_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s));
+            drawn != nullptr ? *drawn : ok_draw_random_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s));
         if (r.crashed)
         {
             // Agent::reset (Agent.cpp:123-135); DisplacementStats deliberately untouched
@@ -576,6 +630,18 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
 #if !defined(OKENV_MAX_SPLIT)
 #define OKENV_MAX_SPLIT 8
 #endif
+// Wave issue priority (s_setprio; a scheduling hint, never visible in results): 0 none, 1 by the amount of phase-2 work,
+// 2 by how far the wave lags behind the leading wave of its SIMD (measured on C2: 16.2 / 15.6 / 13.3 us per step)
+#if !defined(OKENV_PRIO)
+#define OKENV_PRIO 2
+#endif
+#if !defined(OKENV_PRIO_N1)
+#define OKENV_PRIO_N1 8
+#define OKENV_PRIO_N2 16
+#endif
+#if !defined(OKENV_PRIO_STEP)
+#define OKENV_PRIO_STEP 1
+#endif
 constexpr int kMaxSplit = OKENV_MAX_SPLIT; // intervals a pending ray is cut into at most
 
 template <int kPolicy>
@@ -583,7 +649,9 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
     // Q-learning scans the centre line every step (reward = progress along it): keep it in LDS, behind the image
-    float    *lds_cx     = reinterpret_cast<float *>(ok_lds + off_coop);
+    // LDS behind the image: four progress words (one per SIMD, see OKENV_PRIO below), then the Q-learning data
+    uint32_t *lds_progress = reinterpret_cast<uint32_t *>(ok_lds + off_coop);
+    float    *lds_cx     = reinterpret_cast<float *>(ok_lds + off_coop + 16);
     float    *lds_cy     = lds_cx + p.P;
     uint16_t *lds_cstart = reinterpret_cast<uint16_t *>(lds_cy + p.P);
     uint16_t *lds_cidx   = lds_cstart + (p.geom.nx * p.geom.ny + 1);
@@ -602,7 +670,13 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
                 lds_cidx[i] = p.cl_idx[i];
         }
     }
+    if (threadIdx.x < 4)
+        lds_progress[threadIdx.x] = 0U;
     const OkPolyView view = okSetupView<kGridLds>(p, ok_lds); // ends with a barrier
+#if OKENV_PRIO == 2
+    // which of the CU's four SIMDs this wave runs on (HW_REG_HW_ID bits 5:4): waves of one SIMD compete for its issue slots
+    const uint32_t my_simd = (__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4)) & 3U;
+#endif
 
     const int  G        = p.G;
     const long gl       = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -640,6 +714,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
 
 #if defined(OKENV_STAMPS)
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long wprof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // walk-internal stamps: [0..4] phase 1, [5..9] phase 2
 #define OK_STAMP(i)                                                                                                    \
     do                                                                                                                 \
     {                                                                                                                  \
@@ -647,12 +722,36 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
         acc[i] += now_ - last_;                                                                                        \
         last_ = now_;                                                                                                  \
     } while (0)
+#define OK_WPROF(o) , wprof + (o)
     unsigned long long last_ = __builtin_amdgcn_s_memtime();
+    acc[2]                   = __builtin_amdgcn_s_memrealtime(); // wave start / end on the chip-wide 100 MHz clock
 #else
 #define OK_STAMP(i)
+#define OK_WPROF(o)
 #endif
+    ok_random_action ra_blk{}; // bench driver: this lane's share of the current block of drawn actions
     for (int s = 0; s < p.n_steps; ++s)
     {
+#if OKENV_PRIO == 2
+        // A launch ends with its slowest wave, and a wave is slow for many steps in a row (its agent sits where rays are long).
+        // Waves of one SIMD share its issue slots: the further a wave lags behind the leader of its SIMD, the higher its
+        // issue priority.  Purely a scheduling hint: no effect on results.
+        {
+            uint32_t leader = 0U;
+            if ((threadIdx.x & 63U) == 0U)
+                leader = atomicMax(&lds_progress[my_simd], static_cast<uint32_t>(s));
+            leader          = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(leader)));
+            const int behind = static_cast<int>(leader) - s;
+            if (behind >= 3 * OKENV_PRIO_STEP)
+                __builtin_amdgcn_s_setprio(3);
+            else if (behind >= 2 * OKENV_PRIO_STEP)
+                __builtin_amdgcn_s_setprio(2);
+            else if (behind >= OKENV_PRIO_STEP)
+                __builtin_amdgcn_s_setprio(1);
+            else
+                __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         if (kPolicy == kPolicyMlp)
             okPolicyAction(p, a, r, G, ag, last_dist, ray_ok);
         if (kPolicy == kPolicyQ)
@@ -661,9 +760,33 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
                                           qc0, qc1, qc2);
             ok_q_action_values(q_action, &ag.thr, &ag.steer);
         }
+        // Bench driver (kActionsPhiloxReset): an action depends on (seed, agent, step) only, so lane r of the agent's group
+        // draws the action of step s_blk + r and one Philox evaluation serves G steps; each step then fetches its own
+        // (same draws, same bits as one evaluation per step).
+        ok_random_action        ra_now{};
+        const ok_random_action *drawn = nullptr;
+        if (kPolicy == kPolicyNone && p.action_source == kActionsPhiloxReset)
+        {
+            const int idx = s & (G - 1);
+            if (idx == 0)
+                ra_blk = ok_draw_random_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s + r));
+            if (G == 64)
+            { // one agent per wave: the source lane is wave-uniform
+                ra_now.throttle   = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ra_blk.throttle), idx));
+                ra_now.steer      = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ra_blk.steer), idx));
+                ra_now.reset_word = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ra_blk.reset_word), idx));
+            }
+            else
+            {
+                ra_now.throttle   = __shfl(ra_blk.throttle, idx, G);
+                ra_now.steer      = __shfl(ra_blk.steer, idx, G);
+                ra_now.reset_word = static_cast<uint32_t>(__shfl(static_cast<int>(ra_blk.reset_word), idx, G));
+            }
+            drawn = &ra_now;
+        }
         float sr, cr;
         float rdx = 1.F, rdy = 0.F;
-        okAgentPreStep(p, ag, a, s, sr, cr, ray_deg, &rdy, &rdx);
+        okAgentPreStep(p, ag, a, s, sr, cr, ray_deg, &rdy, &rdx, drawn);
         const float ox     = ag.pos_x + p.sensor_offset * cr;
         const float oy     = ag.pos_y + p.sensor_offset * sr;
         const bool  casts  = ray_ok && !ag.crashed;
@@ -676,7 +799,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
         if (casts)
         {
             const OkIntervalResult r1 =
-                ok_cast_poly_interval<false>(view, ox, oy, rdx, rdy, 0.F, phase1_range, nullptr, nullptr, nullptr);
+                ok_cast_poly_interval<false>(view, ox, oy, rdx, rdy, 0.F, phase1_range, nullptr, nullptr, nullptr OK_WPROF(0));
             min_t      = r1.min_t;
             unfinished = !r1.conclusive;
             t_reached  = r1.t_reached;
@@ -688,6 +811,12 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
         {
             const int lane = static_cast<int>(__lane_id());
             const int n    = __popcll(pending);
+#if OKENV_PRIO == 1 // waves with much phase-2 work get issue priority
+            if (n > OKENV_PRIO_N2)
+                __builtin_amdgcn_s_setprio(2);
+            else if (n > OKENV_PRIO_N1)
+                __builtin_amdgcn_s_setprio(1);
+#endif
             int       m    = 64 / n;
             m              = m > kMaxSplit ? kMaxSplit : m;
             // rank of an unfinished lane among the pending ones; rank -> lane through a forward permute
@@ -716,10 +845,13 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
                 const float dt = (OK_SENSOR_RANGE - t0) * inv_m;
                 const float ta = t0 + static_cast<float>(j) * dt;
                 const float tb = (j + 1 == m) ? OKRC_INF : t0 + static_cast<float>(j + 1) * dt;
-                const OkIntervalResult r2 = ok_cast_poly_interval<false>(view, tox, toy, tdx, tdy, ta, tb, nullptr, nullptr, nullptr);
+                const OkIntervalResult r2 = ok_cast_poly_interval<false>(view, tox, toy, tdx, tdy, ta, tb, nullptr, nullptr, nullptr OK_WPROF(5));
                 found                     = r2.min_t;
             }
             // min over the m lanes of a ray (consecutive lanes), then back to the owner
+            const int first = unfinished ? rank * m : 0;
+            float     mine  = OK_SENSOR_RANGE;
+#if !defined(OKENV_GATHER_COMBINE) // shuffle tree over the m lanes, then one pull by the owner (measured faster than the owner gathering all m)
 #pragma unroll
             for (int off = 1; off < kMaxSplit; off <<= 1)
             {
@@ -727,9 +859,20 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
                 if (j + off < m && other < found)
                     found = other;
             }
-            const float mine = __shfl(found, unfinished ? rank * m : 0, 64);
+            mine = __shfl(found, first, 64);
+#else
+#pragma unroll
+            for (int i = 0; i < kMaxSplit; ++i)
+            {
+                const float other = __shfl(found, first + (i < m ? i : 0), 64);
+                mine              = (other < mine) ? other : mine;
+            }
+#endif
             if (unfinished && mine < min_t)
                 min_t = mine;
+#if OKENV_PRIO == 1
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         OK_STAMP(3);
 
@@ -878,12 +1021,29 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
         p.q_prev_idx[a] = q_prev;
     }
 #if defined(OKENV_STAMPS)
+    acc[4] = __builtin_amdgcn_s_memrealtime();
     if ((threadIdx.x & 63) == 0)
     { // diagnostic build only: per-wave cycle sums go to the (otherwise unused here) rel_x tail... a dedicated buffer
         unsigned long long *dbg = reinterpret_cast<unsigned long long *>(const_cast<uint32_t *>(p.g_refs32));
         const long          w   = gl >> 6;
         for (int i = 0; i < 6; ++i)
-            dbg[w * 6 + i] = acc[i];
+            dbg[w * 16 + i] = acc[i];
+    }
+    { // walk-internal stamps of the lane that spent the longest inside the walks (its view has the fewest gaps)
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(const_cast<uint32_t *>(p.g_refs32));
+        const long          w   = gl >> 6;
+        unsigned long long  tot = 0;
+        for (int i = 0; i < 10; ++i)
+            tot += wprof[i];
+        unsigned long long best = tot;
+        for (int off = 1; off < 64; off <<= 1)
+        {
+            const unsigned long long o = __shfl_xor(best, off, 64);
+            best                       = o > best ? o : best;
+        }
+        if (tot == best)
+            for (int i = 0; i < 10; ++i)
+                dbg[w * 16 + 6 + i] = wprof[i];
     }
 #endif
     if (agent_ok && r == 0)

@@ -91,4 +91,28 @@ extern "C"
         }
         return 0;
     }
+
+    // ok_first_hit_update (division-free common path) next to the reference's sequence ok_ray_segment, element by element:
+    // out_new[i] / out_ref[i] = updated first-hit parameter of candidate i
+    __attribute__((visibility("default"))) int gridcheck_first_hit_update(int          n,
+                                                                          const float *ox,
+                                                                          const float *oy,
+                                                                          const float *dx,
+                                                                          const float *dy,
+                                                                          const float *ax,
+                                                                          const float *ay,
+                                                                          const float *bx,
+                                                                          const float *by,
+                                                                          const float *min_t,
+                                                                          float       *out_new,
+                                                                          float       *out_ref)
+    {
+        for (int i = 0; i < n; ++i)
+        {
+            out_new[i] = ok_first_hit_update(ox[i], oy[i], dx[i], dy[i], OkPoint{ax[i], ay[i]}, OkPoint{bx[i], by[i]}, min_t[i]);
+            float t;
+            out_ref[i] = ok_ray_segment(ox[i], oy[i], dx[i], dy[i], ax[i], ay[i], bx[i], by[i], min_t[i], t) ? t : min_t[i];
+        }
+        return 0;
+    }
 }

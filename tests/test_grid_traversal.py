@@ -22,6 +22,7 @@ def gridcheck():
     subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src], check=True)
     G = C.CDLL(so)
     G.gridcheck_cast.argtypes = [O.f32p, C.c_int, C.c_float, O.f32p, O.f32p, O.f32p, C.c_int, O.f32p, O.u32p, O.u32p, O.i32p, C.c_int, O.u32p]
+    G.gridcheck_first_hit_update.argtypes = [C.c_int] + [O.f32p] * 11
     return G
 
 
@@ -90,3 +91,53 @@ def test_degenerate_segment_sets(oracle, gridcheck):
         for form in (0, 1, 3):
             assert gridcheck.gridcheck_cast(flat, segs.shape[0], 16.0, ox, oy, ang, n, got, tests, cells, info, form, points) == 0
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), form
+
+
+def test_first_hit_update_equals_reference_sequence(gridcheck):
+    """ok_first_hit_update (the exact test with its two IEEE divisions taken out of the common path) returns the bits of
+    the reference's sequence (CollisionChecker.cu:8-35 as restated in ok_ray_segment) -- on realistic candidates, on
+    boundary cases of every comparison (s = 0, s = 1, t = 0, t = min_t to the last ulp), and on irregular values
+    (zeros, denormals, tiny and huge magnitudes, infinities, NaNs) in every argument."""
+    rng = np.random.default_rng(7)
+    n = 400000
+    f = np.float32
+    ox = rng.uniform(100, 1500, n).astype(f)
+    oy = rng.uniform(100, 1300, n).astype(f)
+    ang = rng.uniform(-np.pi, np.pi, n)
+    dx, dy = np.cos(ang).astype(f), np.sin(ang).astype(f)
+    # segments of a few px near the ray: many real hits
+    t_true = rng.uniform(-5, 220, n)
+    s_true = rng.uniform(-0.3, 1.3, n)
+    seg_ang = rng.uniform(-np.pi, np.pi, n)
+    length = rng.uniform(0.03, 6.0, n)
+    hx, hy = ox + t_true * dx, oy + t_true * dy
+    ax = (hx - s_true * length * np.cos(seg_ang)).astype(f)
+    ay = (hy - s_true * length * np.sin(seg_ang)).astype(f)
+    bx = (ax + length * np.cos(seg_ang)).astype(f)
+    by = (ay + length * np.sin(seg_ang)).astype(f)
+    min_t = np.where(rng.random(n) < 0.5, f(200.0), rng.uniform(0, 200, n)).astype(f)
+    k = n // 8
+    # boundary cases: the segment starts or ends exactly on the ray's line / at the origin; min_t equal to the hit itself
+    ax[:k], ay[:k] = (ox + f(7.0) * dx)[:k], (oy + f(7.0) * dy)[:k]                      # s == 0 up to rounding
+    bx[k:2 * k], by[k:2 * k] = (ox + f(9.0) * dx)[k:2 * k], (oy + f(9.0) * dy)[k:2 * k]  # s == 1 up to rounding
+    ax[2 * k:3 * k], ay[2 * k:3 * k] = ox[2 * k:3 * k], oy[2 * k:3 * k]                  # t == 0, s == 0
+    # axis-aligned rays and segments: exact zeros in the products
+    dx[3 * k:3 * k + k // 2], dy[3 * k:3 * k + k // 2] = f(1.0), f(0.0)
+    ax[3 * k:3 * k + k // 4] = bx[3 * k:3 * k + k // 4]
+    specials = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-38, 1e-30, -1e-30, 1e-21, 1e-20, 1e-19, 1e-8, -1e-8, 9.9e-9, 1.0, -1.0, 1e9, 1e10,
+                         1.1e10, 1e19, -1e19, 1e30, 3e38, np.inf, -np.inf, np.nan], dtype=f)
+    m = 60000
+    base = 4 * k
+    for arr in (ox, oy, dx, dy, ax, ay, bx, by, min_t):
+        pick = rng.random(m) < 0.25
+        arr[base:base + m] = np.where(pick, specials[rng.integers(0, specials.size, m)], arr[base:base + m])
+    out_new = np.zeros(n, dtype=f)
+    out_ref = np.zeros(n, dtype=f)
+    args = [np.ascontiguousarray(a) for a in (ox, oy, dx, dy, ax, ay, bx, by, min_t)]
+    # first pass; second pass with min_t set to the first pass's result (t == min_t exactly: ties must be kept)
+    for _ in range(2):
+        gridcheck.gridcheck_first_hit_update(n, *args, out_new, out_ref)
+        assert np.array_equal(out_new.view(np.uint32), out_ref.view(np.uint32))
+        args[8] = out_ref.copy()
+    hits = np.count_nonzero(out_ref.view(np.uint32) != min_t.view(np.uint32))
+    assert hits > n // 20  # the sample does exercise the accepting path

@@ -1,0 +1,236 @@
+// wave_model.cpp -- development aid: lock-step (SIMD) trip-count model of the cooperative step's raycast.
+//
+// Replays the two-phase walk of okStepCoopKernel for waves of 64 rays on the CPU with the product's own traversal
+// header, records per lane and per loop iteration what the lane did, and reduces that to what a 64-lane wave executes
+// when all lanes run the loops in lock step (trip count of a loop = max over its active lanes).  Output: per wave-step
+// averages of cell iterations, chunk iterations, point-pair iterations, exact-test iterations, and the lane utilisation
+// of each, for a given cell size / phase-1 range / split width.  Used to rank design alternatives without GPU time.
+//
+// build: g++ -O2 -std=c++17 -ffp-contract=off -shared -fPIC -I include -I openkitchen_amd/csrc -o tools/_build/libwavemodel.so tools/wave_model.cpp
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "../openkitchen_amd/csrc/ok_grid.h"
+
+namespace
+{
+double g_cls[5] = {0, 0, 0, 0, 0};
+struct ChunkRec
+{
+    uint16_t pairs;  // point-pair iterations of the chunk
+    uint16_t exact;  // exact tests run after it
+};
+struct CellRec
+{
+    std::vector<ChunkRec> chunks;
+};
+struct LaneTrace
+{
+    std::vector<CellRec> cells;
+    float                min_t      = OK_SENSOR_RANGE;
+    float                t_reached  = 0.F;
+    bool                 conclusive = true;
+};
+
+// ok_cast_poly_interval with recording (same control flow)
+LaneTrace traceInterval(const OkPolyView &v, float ox, float oy, float rdx, float rdy, float t_a, float t_b, int pair_batch)
+{
+    LaneTrace         tr;
+    const OkGridGeom &g = v.g;
+    OkWalk            w;
+    if (!w.init(g, ox, oy, rdx, rdy, t_a))
+        return tr;
+    const float tol   = v.side_tol;
+    float       min_t = OK_SENSOR_RANGE;
+    OkCellHdr   h     = v.hdr[w.iy * g.nx + w.ix];
+    for (int guard = g.nx + g.ny + 2; guard > 0; --guard)
+    {
+        CellRec   cr;
+        OkCellHdr hc = h;
+        while (true)
+        {
+            const uint32_t k0 = hc.w0 & OKPOLY_IDX_MASK;
+            const uint32_t n  = (hc.w0 >> OKPOLY_IDX_BITS) & OKPOLY_N_MASK;
+            uint32_t       skip = 0U;
+            float          sp   = 0.F;
+            const float    c_ray = __builtin_fmaf(ox, rdy, -(oy * rdx));
+            for (uint32_t i = 0; i < n; i += 8)
+                for (uint32_t j = 0; j < 8; ++j)
+                {
+                    const OkPoint pt = v.slots[k0 + i + j];
+                    const float   sj = __builtin_fmaf(pt.x, rdy, __builtin_fmaf(pt.y, -rdx, -c_ray));
+                    skip             = okShiftInSign(skip, tol - __builtin_fabsf(okMed3(sp, sj, 0.F)));
+                    sp               = sj;
+                }
+            uint32_t       cand = ~(skip | hc.brk);
+            const uint32_t top  = k0 + ((n + 7U) & ~7U) - 2U;
+            ChunkRec c{static_cast<uint16_t>((n + 8 * pair_batch - 1) / (8 * pair_batch)), static_cast<uint16_t>(__builtin_popcount(cand))};
+            while (cand != 0U)
+            {
+                const uint32_t z = static_cast<uint32_t>(__builtin_clz(cand));
+                cand &= ~(0x80000000U >> z);
+                const uint32_t k = top - (31U - z);
+                // classify (statistics only)
+                {
+                    const OkPoint a = v.slots[k], b = v.slots[k + 1];
+                    const float sdx = b.x - a.x, sdy = b.y - a.y, den = rdx * sdy - rdy * sdx;
+                    const float tt = ((a.x - ox) * sdy - (a.y - oy) * sdx) / den, ss = ((a.x - ox) * rdy - (a.y - oy) * rdx) / den;
+                    int cls = 0; // 0 accepted-range (0<=t<=min_t, s ok), 1 behind (t<0), 2 beyond current hit, 3 s outside, 4 parallel
+                    if (__builtin_fabsf(den) < OK_PARALLEL_EPS) cls = 4;
+                    else if (tt < 0.F) cls = 1;
+                    else if (tt > min_t) cls = 2;
+                    else if (!(ss >= 0.F && ss <= 1.F)) cls = 3;
+                    g_cls[cls] += 1;
+                }
+                min_t = okExactSlot(v, k, ox, oy, rdx, rdy, min_t);
+            }
+            cr.chunks.push_back(c);
+            if (((hc.w0 >> (OKPOLY_IDX_BITS + 6)) & 1U) == 0U)
+                break;
+            hc = *reinterpret_cast<const OkCellHdr *>(&v.slots[k0 + n]);
+        }
+        tr.cells.push_back(cr);
+        const float t_exit = w.exitT();
+        tr.min_t           = min_t;
+        if (__builtin_fminf(min_t, w.t_out) <= t_exit)
+        {
+            tr.t_reached  = t_exit;
+            tr.conclusive = true;
+            return tr;
+        }
+        if (t_exit >= t_b)
+        {
+            tr.t_reached  = t_exit;
+            tr.conclusive = false;
+            return tr;
+        }
+        if (!w.advance(g))
+        {
+            tr.t_reached  = OK_SENSOR_RANGE;
+            tr.conclusive = true;
+            return tr;
+        }
+        h = v.hdr[w.iy * g.nx + w.ix];
+    }
+    tr.conclusive = true;
+    return tr;
+}
+
+struct WaveCount
+{
+    double cell_it = 0, chunk_it = 0, pair_it = 0, exact_it = 0;             // lock-step iterations
+    double cell_lanes = 0, chunk_lanes = 0, pair_lanes = 0, exact_lanes = 0; // active lane-iterations
+    void   add(const std::vector<LaneTrace> &lanes)
+    {
+        size_t max_cells = 0;
+        for (auto &l : lanes)
+            max_cells = std::max(max_cells, l.cells.size());
+        for (size_t c = 0; c < max_cells; ++c)
+        {
+            cell_it += 1;
+            size_t max_chunks = 0;
+            for (auto &l : lanes)
+                if (c < l.cells.size())
+                {
+                    cell_lanes += 1;
+                    max_chunks = std::max(max_chunks, l.cells[c].chunks.size());
+                }
+            for (size_t k = 0; k < max_chunks; ++k)
+            {
+                chunk_it += 1;
+                int mp = 0, me = 0;
+                for (auto &l : lanes)
+                    if (c < l.cells.size() && k < l.cells[c].chunks.size())
+                    {
+                        chunk_lanes += 1;
+                        mp = std::max<int>(mp, l.cells[c].chunks[k].pairs);
+                        me = std::max<int>(me, l.cells[c].chunks[k].exact);
+                        pair_lanes += l.cells[c].chunks[k].pairs;
+                        exact_lanes += l.cells[c].chunks[k].exact;
+                    }
+                pair_it += mp;
+                exact_it += me;
+            }
+        }
+    }
+};
+} // namespace
+
+extern "C" __attribute__((visibility("default"))) int wavemodel_run(const float *segs_xyxy,
+                                                                     int          S,
+                                                                     float        cell,
+                                                                     const float *pos_x,
+                                                                     const float *pos_y,
+                                                                     const float *rot_deg,
+                                                                     int          n_agents,
+                                                                     const float *ray_deg,
+                                                                     int          R, // <= 64, one agent per wave (G = 64)
+                                                                     float        phase1_range,
+                                                                     int          max_split,
+                                                                     int          pair_batch,
+                                                                     double      *out /* 20 doubles */)
+{
+    const OkSeg *segs = reinterpret_cast<const OkSeg *>(segs_xyxy);
+    OkGridHost   gh   = okBuildGrid(segs, static_cast<size_t>(S), cell);
+    OkPolyImage  img  = okBuildPolyImage(segs, static_cast<size_t>(S), gh);
+    if (!img.ok)
+        return -1;
+    OkPolyView pv{};
+    pv.g        = gh.g;
+    pv.slots    = reinterpret_cast<const OkPoint *>(img.bytes.data());
+    pv.hdr      = reinterpret_cast<const OkCellHdr *>(img.bytes.data() + img.off_hdr);
+    pv.side_tol = img.side_tol;
+    WaveCount p1, p2;
+    for (double &x : g_cls) x = 0;
+    double    n_pending = 0, waves_with_p2 = 0;
+    for (int a = 0; a < n_agents; ++a)
+    {
+        float sr, cr;
+        ok_sincosf(OK_DEG2RAD * rot_deg[a], &sr, &cr);
+        const float            ox = pos_x[a], oy = pos_y[a];
+        std::vector<LaneTrace> l1(64);
+        std::vector<float>     dx(64), dy(64);
+        std::vector<int>       pend;
+        for (int r = 0; r < R; ++r)
+        {
+            ok_sincosf(OK_DEG2RAD * (rot_deg[a] + ray_deg[r]), &dy[r], &dx[r]);
+            l1[r] = traceInterval(pv, ox, oy, dx[r], dy[r], 0.F, phase1_range, pair_batch);
+            if (!l1[r].conclusive)
+                pend.push_back(r);
+        }
+        p1.add(l1);
+        if (!pend.empty())
+        {
+            waves_with_p2 += 1;
+            n_pending += pend.size();
+            const int n = static_cast<int>(pend.size());
+            int       m = 64 / n;
+            m           = m > max_split ? max_split : m;
+            std::vector<LaneTrace> l2;
+            for (int lane = 0; lane < 64; ++lane)
+            {
+                const int q = lane / m, j = lane - q * m;
+                if (q >= n)
+                    continue;
+                const int   r  = pend[q];
+                const float t0 = l1[r].t_reached;
+                const float dt = (OK_SENSOR_RANGE - t0) / static_cast<float>(m);
+                const float ta = t0 + static_cast<float>(j) * dt;
+                const float tb = (j + 1 == m) ? OKRC_INF : t0 + static_cast<float>(j + 1) * dt;
+                l2.push_back(traceInterval(pv, ox, oy, dx[r], dy[r], ta, tb, pair_batch));
+            }
+            p2.add(l2);
+        }
+    }
+    const double W = n_agents;
+    double      *o = out;
+    *o++ = p1.cell_it / W;  *o++ = p1.chunk_it / W;  *o++ = p1.pair_it / W;  *o++ = p1.exact_it / W;
+    *o++ = p1.cell_lanes / W;  *o++ = p1.chunk_lanes / W;  *o++ = p1.pair_lanes / W;  *o++ = p1.exact_lanes / W;
+    *o++ = p2.cell_it / W;  *o++ = p2.chunk_it / W;  *o++ = p2.pair_it / W;  *o++ = p2.exact_it / W;
+    *o++ = p2.cell_lanes / W;  *o++ = p2.chunk_lanes / W;  *o++ = p2.pair_lanes / W;  *o++ = p2.exact_lanes / W;
+    *o++ = n_pending / W;  *o++ = waves_with_p2 / W;  *o++ = static_cast<double>(img.bytes.size());  *o++ = img.max_slots_per_cell;
+    std::printf("    exact tests per wave-step by outcome: accepted %.1f behind %.1f beyond-hit %.1f s-outside %.1f parallel %.1f\n", g_cls[0] / W, g_cls[1] / W, g_cls[2] / W, g_cls[3] / W, g_cls[4] / W);
+    return 0;
+}

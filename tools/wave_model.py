@@ -1,0 +1,66 @@
+"""Development aid: lock-step trip counts of the cooperative raycast (tools/wave_model.cpp) on bench-recipe poses.
+
+usage: python tools/wave_model.py [track] [agents] [rays]
+Poses come from the CPU oracle's rollout of the bench recipe (test infrastructure used as a pose generator only).
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _oracle as O  # noqa: E402
+
+SO = os.path.join(ROOT, "tools", "_build", "libwavemodel.so")
+
+
+def build():
+    os.makedirs(os.path.dirname(SO), exist_ok=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                    "-I", os.path.join(ROOT, "openkitchen_amd", "csrc"), "-o", SO, os.path.join(ROOT, "tools", "wave_model.cpp")], check=True)
+    L = C.CDLL(SO)
+    f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+    L.wavemodel_run.argtypes = [f32p, C.c_int, C.c_float, f32p, f32p, f32p, C.c_int, f32p, C.c_int, C.c_float, C.c_int, C.c_int,
+                                np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")]
+    return L
+
+
+def poses(track, N, R, steps=60, seed=1234):
+    O.build_oracle(with_ref=False)
+    fan = O.default_ray_fan(R)
+    env = O.OracleEnv(track.segments, N, R, fan, (track.x, track.y, track.heading))
+    env.init_bench_state(0, 0)
+    env.rollout_random(steps, seed, 0, 0, threads=8)
+    s = env.snapshot()
+    keep = s["crashed"] == 0
+    return s["pos_x"][keep].copy(), s["pos_y"][keep].copy(), s["rot"][keep].copy(), fan
+
+
+def main():
+    tname = sys.argv[1] if len(sys.argv) > 1 else "Silverstone"
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+    R = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+    L = build()
+    track = O.Track(tname)
+    px, py, rot, fan = poses(track, N, R)
+    print("%s: %d live poses, %d rays" % (tname, px.size, R))
+    hdr = ("(pairs column = 8-slot rounds)\ncell  T1 split pb |  p1: cells chunks pairs exact (util: cell pair exact) |  p2: cells chunks pairs exact (util) | pend  p2frac | image")
+    print(hdr)
+    for cell, t1, split, pb in [(20, 48, 8, 1), (24, 48, 8, 1), (24, 40, 8, 1), (24, 56, 8, 1), (28, 48, 8, 1), (20, 48, 16, 1)]:
+        out = np.zeros(20)
+        rc = L.wavemodel_run(track.segments, track.S, float(cell), px, py, rot, px.size, fan, R, float(t1), split, pb, out)
+        if rc != 0:
+            print("cell %g: image not encodable" % cell)
+            continue
+        o = out
+        print("%4g %3g %4d %3d | %6.2f %6.2f %6.2f %6.2f (%.2f %.2f %.2f) | %6.2f %6.2f %6.2f %6.2f (%.2f %.2f %.2f) | %5.1f %5.2f | %d B max %d"
+              % (cell, t1, split, pb, o[0], o[1], o[2], o[3], o[4] / max(o[0], 1e-9) / 64, o[6] / max(o[2], 1e-9) / 64, o[7] / max(o[3], 1e-9) / 64,
+                 o[8], o[9], o[10], o[11], o[12] / max(o[8], 1e-9) / 64, o[14] / max(o[10], 1e-9) / 64, o[15] / max(o[11], 1e-9) / 64,
+                 o[16], o[17], int(o[18]), int(o[19])))
+
+
+if __name__ == "__main__":
+    main()
