@@ -250,6 +250,8 @@ def main():
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2: headline (random actions); c3/c4: EvolutionaryRacer generations (population 8192 x 32 rays per GPU, "
                          "Monza / Spa, fused MLP policy, score, select, mate; c4 adds the per-generation RCCL fitness all-gather)")
+    ap.add_argument("--repeats", type=int, default=30,
+                    help="the K-step timed region is run this many times back to back (state continues); `value` is from the median")
     ap.add_argument("--generations", type=int, default=5)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, default).  gloo + --single-device rehearses the multi-process path on a one-GPU box")
@@ -318,24 +320,32 @@ def main():
     # ---- warm-up (untimed) ----
     run_steps(args.warmup, 0)
     fence()
-    # ---- timed region: exactly K steps ----
+    # ---- timed region: exactly K steps between two fences, repeated `repeats` times back to back (the state simply
+    # continues).  One region at the driver's --steps 20 is a single 0.3 ms launch, so a single sample says little: the
+    # headline is the MEDIAN region, min / max / spread are reported beside it.  Every region's time is the max over ranks.
+    repeats = max(1, args.repeats)
     env.set_timing(True)
-    t0 = time.perf_counter()
-    run_steps(args.steps, args.warmup)
-    env.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    region_s = []
+    for rep in range(repeats):
+        fence()
+        t0 = time.perf_counter()
+        run_steps(args.steps, args.warmup + rep * args.steps)
+        env.sync()
+        torch.cuda.synchronize()
+        region_s.append(time.perf_counter() - t0)
     sharding.barrier(device_ids=[local_rank])
     kernel_ms, launches = env.get_timing()
     env.set_timing(False)
-    elapsed_max = sharding.max_over_ranks(elapsed, device=args.tensor_dev)
+    region_s = sharding.max_over_ranks_list(region_s, device=args.tensor_dev)
+    elapsed_max = float(np.median(region_s))
+    steps_done = args.warmup + repeats * args.steps
 
     # ---- secondary figure: one launch per step (what a host-side policy between steps would see) ----
     one_steps = 0 if args.headline_only else min(args.steps, 500)
     env.sync()
     t1 = time.perf_counter()
     for s in range(one_steps):
-        env.rollout_random(1, args.seed, agent_base, args.warmup + args.steps + s)
+        env.rollout_random(1, args.seed, agent_base, steps_done + s)
     env.sync()
     one_elapsed = time.perf_counter() - t1
 
@@ -367,19 +377,27 @@ def main():
         value = total_agents * args.steps / elapsed_max
         b_alg = algorithmic_bytes_per_agent_step(N, R, track.S)
         avg_launch_s = (kernel_ms * 1e-3) / max(launches, 1)
-        steps_per_launch_avg = args.steps / max(launches, 1)
+        steps_per_launch_avg = repeats * args.steps / max(launches, 1)
         bytes_per_launch = b_alg * N * steps_per_launch_avg
         achieved_gbs = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        kernel_us_per_step = kernel_ms * 1e3 / (repeats * args.steps)
         traffic, valu = None, None
-        try:  # measured HBM bytes and VALU instructions per launch from the committed PMC profile, if the configuration matches
+        try:  # measured HBM bytes and issue statistics from the committed PMC profile of this kernel, kept PER AGENT-STEP so
+            # that they apply to any --steps / --steps-per-launch; only the workload has to match
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-            if (tj["agents"], tj["rays"], tj["track"], tj["steps_per_launch"]) == (N, R, args.track, spl):
-                traffic = tj["hbm_bytes_per_launch"]
-                # the bound that actually binds: VALU issue.  One wave64 VALU instruction per 4 cycles per SIMD, 1024 SIMDs,
-                # 2.4 GHz peak clock; instructions from PMC (profile build of the same kernel), time from this run's HIP events
-                avg_s = (kernel_ms * 1e-3) / max(launches, 1)
-                valu = {"bound": "valu-issue", "insts_per_launch": tj["valu_insts_per_launch"], "cycles_per_inst": 4, "simds": 1024,
-                        "clock_ghz": 2.4, "frac": tj["valu_insts_per_launch"] * 4.0 / (1024 * avg_s * 2.4e9) if avg_s > 0 else None,
+            if (tj["agents"], tj["rays"], tj["track"]) == (N, R, args.track):
+                traffic = tj["hbm_bytes_per_agent_step"] * N * steps_per_launch_avg
+                w = tj["per_wave_step"]
+                waves_per_simd = N * info["lanes_per_agent"] / 64.0 / 1024.0
+                cyc_per_step = kernel_us_per_step * 1e-6 * tj["clock_ghz"] * 1e9
+                valu = {"bound": "latency (per-wave dependent chain), not VALU issue",
+                        "valu_insts_per_wave_step": w["valu"], "salu_insts_per_wave_step": w["salu"], "lds_insts_per_wave_step": w["lds"],
+                        "cycles_per_valu_inst": 2, "simds": 1024, "clock_ghz": tj["clock_ghz"],
+                        # share of a SIMD's issue cycles its waves' VALU instructions take at 2 cycles each
+                        # (/opt/skills/guides/MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles on the SIMD-32)
+                        "simd_valu_issue_frac": w["valu"] * waves_per_simd * 2.0 / cyc_per_step if cyc_per_step > 0 else None,
+                        "wave_time_active_frac": w["active_frac"], "wave_time_wait_frac": w["wait_frac"],
+                        "wave_time_issue_stall_frac": w["issue_stall_frac"], "valu_lane_utilisation": w.get("lane_util"),
                         "source": tj["source"]}
         except Exception:
             traffic, valu = None, None
@@ -391,6 +409,10 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
+            "repeats": repeats,
+            "ms_per_step_min": min(region_s) / args.steps * 1e3,
+            "ms_per_step_max": max(region_s) / args.steps * 1e3,
+            "spread": (max(region_s) - min(region_s)) / elapsed_max if elapsed_max > 0 else None,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -411,12 +433,14 @@ def main():
             "callers": callers,
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/hbm_traffic.json)",
+                         "traffic_unit": "HBM bytes per launch = measured bytes per agent-step (PMC FETCH_SIZE x2 + WRITE_SIZE, "
+                                         "profiles/hbm_traffic.json) x agents x steps per launch",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel": "okStepCoopKernel" if info["grid_in_lds"] and R <= 64 else "okStepKernel",
                          "algorithmic_bytes_per_agent_step": b_alg,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": int(launches),
-                         "kernel_only_agent_steps_per_sec": N * args.steps / (kernel_ms * 1e-3) if kernel_ms > 0 else None,
+                         "kernel_only_agent_steps_per_sec": N * repeats * args.steps / (kernel_ms * 1e-3) if kernel_ms > 0 else None,
+                         "kernel_us_per_step": kernel_us_per_step,
                          "note": "VALU/LDS-bound path: algorithmic HBM traffic is ~0.35 KB per agent-step (BASELINE.md section 5)"},
         }
         result["cpu_baseline"] = None

@@ -323,6 +323,10 @@ OKENV_API int32_t okenv_track_num_segments(okenv_track_t t);
 /* which: 0 x_m, 1 y_m, 2 w_tr_right_m, 3 w_tr_left_m, 4 headings_ (P floats);
  *        5 left_bound_inner_, 6 left_bound_outer_, 7 right_bound_inner_, 8 right_bound_outer_ (2P floats, xy) */
 OKENV_API int okenv_track_get(okenv_track_t t, int32_t which, float *out);
+/* RaceTrack::getNearestDistanceToTrackBoundary and RaceTrack::getDistanceToLaneCenter (Environment/RaceTrack.h:36,39,
+ * RaceTrack.cpp:33-72) for n query points (host pointers; either output may be NULL).  Host-side, like the reference's. */
+OKENV_API int okenv_track_queries(okenv_track_t t, const float *qx, const float *qy, int32_t n, float *out_boundary_distance,
+                                  float *out_lane_center_ratio);
 /* TrackSegments::TrackSegments (Environment/TrackSegments.cu:6-42): 4*P segments, x1,y1,x2,y2 each. */
 OKENV_API int okenv_track_segments(okenv_track_t t, float *out_xyxy);
 

@@ -37,7 +37,7 @@ SYMBOLS = [
     "okenv_get_distances", "okenv_get_flags", "okenv_step", "okenv_collide", "okenv_rollout_random",
     "okenv_init_bench_state", "okenv_nearest_track_idx", "okenv_set_timing", "okenv_get_timing", "okenv_track_load",
     "okenv_track_free", "okenv_track_num_points", "okenv_track_num_segments", "okenv_track_get",
-    "okenv_track_segments", "okenv_debug_sincos", "okenv_debug_cast_rays", "okenv_policy_mlp_create",
+    "okenv_track_segments", "okenv_track_queries", "okenv_debug_sincos", "okenv_debug_cast_rays", "okenv_policy_mlp_create",
     "okenv_policy_mlp_weights_per_agent", "okenv_policy_mlp_get_weights", "okenv_policy_mlp_set_weights",
     "okenv_rollout_policy", "okenv_alive_count", "okenv_reset_all", "okenv_ga_scores", "okenv_ga_select_mate",
     "okenv_q_create", "okenv_q_begin_episode", "okenv_rollout_q", "okenv_q_get_table", "okenv_q_set_table", "okenv_q_get_state",
@@ -119,6 +119,7 @@ def load(build_if_missing=True):
     L.okenv_track_num_segments.argtypes = [vp]
     L.okenv_track_get.argtypes = [vp, i32, vp]
     L.okenv_track_segments.argtypes = [vp, vp]
+    L.okenv_track_queries.argtypes = [vp, vp, vp, i32, vp, vp]
     L.okenv_debug_sincos.argtypes = [i32, vp, vp, vp, i32]
     L.okenv_debug_cast_rays.argtypes = [vp, vp, vp, vp, i32, vp]
     L.okenv_policy_mlp_create.argtypes = [vp, i32, u32, u32]

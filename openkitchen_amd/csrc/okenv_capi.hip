@@ -1549,6 +1549,23 @@ extern "C"
         return OKENV_OK;
     }
 
+    int okenv_track_queries(okenv_track_t t, const float *qx, const float *qy, int32_t n, float *out_boundary_distance,
+                            float *out_lane_center_ratio)
+    {
+        if (!t || !qx || !qy || n < 0)
+            return OKENV_ERR_INVALID;
+        const RaceTrack &rt = *t->track;
+        for (int32_t i = 0; i < n; ++i)
+        {
+            const Vec2d q{qx[i], qy[i]};
+            if (out_boundary_distance)
+                out_boundary_distance[i] = rt.getNearestDistanceToTrackBoundary(q);
+            if (out_lane_center_ratio)
+                out_lane_center_ratio[i] = rt.getDistanceToLaneCenter(q);
+        }
+        return OKENV_OK;
+    }
+
     int okenv_track_segments(okenv_track_t t, float *out_xyxy)
     {
         if (!t || !out_xyxy)

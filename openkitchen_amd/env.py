@@ -36,6 +36,23 @@ class Track:
 
     KEYS = ["x", "y", "wr", "wl", "heading", "li", "lo", "ri", "ro"]
 
+    def queries(self, qx, qy):
+        """RaceTrack::getNearestDistanceToTrackBoundary and RaceTrack::getDistanceToLaneCenter (reference
+        Environment/RaceTrack.cpp:33-72) for arrays of query points: (distance to the nearest inner-boundary point [px],
+        distance to the nearest centre-line point / lane width there)."""
+        L = capi.load()
+        qx = np.ascontiguousarray(qx, dtype=np.float32).reshape(-1)
+        qy = np.ascontiguousarray(qy, dtype=np.float32).reshape(-1)
+        assert qx.size == qy.size
+        boundary, lane = np.zeros(qx.size, dtype=np.float32), np.zeros(qx.size, dtype=np.float32)
+        h = C.c_void_p()
+        capi.check(L.okenv_track_load(C.byref(h), self.path.encode()))
+        try:
+            capi.check(L.okenv_track_queries(h, capi.ptr(qx), capi.ptr(qy), qx.size, capi.ptr(boundary), capi.ptr(lane)))
+        finally:
+            L.okenv_track_free(h)
+        return boundary, lane
+
     def __init__(self, name_or_path):
         L = capi.load()
         self.path = track_path(name_or_path)

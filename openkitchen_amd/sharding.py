@@ -50,6 +50,14 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def max_over_ranks_list(values, device="cpu"):
+    """Element-wise MAX all-reduce of a list of python floats (the benchmark's per-repetition elapsed times)."""
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t.tolist()]
+
+
 def all_gather_fitness(local_fitness):
     """All-gather of the per-rank fitness vector (1-D tensor, same length on every rank).  Returns [world, n]."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

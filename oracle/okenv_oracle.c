@@ -260,6 +260,44 @@ ORACLE_API void oracle_nearest_track_idx(const float *cx, const float *cy, int P
     }
 }
 
+/* RaceTrack::getNearestDistanceToTrackBoundary (Environment/RaceTrack.cpp:33-51): the nearest inner-boundary POINT, left
+ * and right interleaved per index; li / ri are xy pairs. */
+ORACLE_API void oracle_boundary_distance(const float *li, const float *ri, int P, const float *qx, const float *qy, int n,
+                                         float *out)
+{
+    for (int j = 0; j < n; ++j) {
+        float min_distance = FLT_MAX;
+        for (int i = 0; i < P; ++i) {
+            float ddx = qx[j] - li[2 * i], ddy = qy[j] - li[2 * i + 1];
+            float distance = ddx * ddx + ddy * ddy;
+            if (distance < min_distance) min_distance = distance;
+            ddx = qx[j] - ri[2 * i];
+            ddy = qy[j] - ri[2 * i + 1];
+            distance = ddx * ddx + ddy * ddy;
+            if (distance < min_distance) min_distance = distance;
+        }
+        out[j] = sqrtf(min_distance);
+    }
+}
+
+/* RaceTrack::getDistanceToLaneCenter (Environment/RaceTrack.cpp:53-72): distance to the nearest centre-line point as a
+ * fraction of the lane width (left + right) at that point. */
+ORACLE_API void oracle_lane_center_distance(const float *cx, const float *cy, const float *w_left, const float *w_right,
+                                            int P, const float *qx, const float *qy, int n, float *out)
+{
+    for (int j = 0; j < n; ++j) {
+        float min_distance = FLT_MAX;
+        int min_dist_idx = 0;
+        for (int i = 0; i < P; ++i) {
+            const float ddx = qx[j] - cx[i], ddy = qy[j] - cy[i];
+            const float distance = ddx * ddx + ddy * ddy;
+            if (distance < min_distance) { min_distance = distance; min_dist_idx = i; }
+        }
+        const float lane_width = w_left[min_dist_idx] + w_right[min_dist_idx];
+        out[j] = sqrtf(min_distance) / lane_width;
+    }
+}
+
 /* ============================================================================================ */
 /* Environment state (SoA mirror of N Agent objects + DisplacementStats + Ray_ hit points)       */
 /* ============================================================================================ */
@@ -427,14 +465,46 @@ ORACLE_API void oracle_env_reset_agents(oracle_env *e, const int32_t *idx, const
     for (int k = 0; k < n; ++k) agent_reset(e, idx[k], x[k], y[k], rot[k]);
 }
 
-/* Environment::resetAgent (Environment/Environment.cpp:79-122) for one agent; the draws and the pose arithmetic are
- * ok_draw_reset / ok_reset_pose of include/okenv_math.h (GetRandomValue -> Philox, static call counter -> ctr). */
+/* GetRandomValue(lo, hi) of raylib (inclusive integer range; un-vendored, global state) drawn from one 32-bit word of the
+ * shared Philox block: lo + floor(word * (hi - lo + 1) / 2^32). */
+static int32_t rand_value_from_word(uint32_t word, int32_t lo, int32_t hi)
+{
+    const uint64_t span = (uint64_t)(hi - lo + 1);
+    return lo + (int32_t)(((uint64_t)word * span) >> 32);
+}
+
+/* Environment::resetAgent (Environment/Environment.cpp:79-122) for one agent, restated line by line.  The three
+ * GetRandomValue calls take words 0, 1, 2 of the Philox block (agent, epoch, 1, 0) -- only the generator is shared with the
+ * device code (include/okenv_math.h), the arithmetic below is this file's own reading of the reference.  `ctr` stands for
+ * the function-static call counter (:88). */
 static void env_reset_agent(oracle_env *e, int i, uint32_t flags, uint32_t seed, uint32_t agent, uint32_t epoch, uint32_t ctr)
 {
-    const ok_reset_draw d = ok_draw_reset(seed, agent, epoch, ctr, (uint32_t)e->P, flags);
-    float x, y, rot;
-    ok_reset_pose(d, e->cx, e->cy, e->chead, e->lane_l, e->lane_r, &x, &y, &rot);
-    agent_reset(e, i, x, y, rot);
+    const ok_u32x4 words = ok_philox4x32(agent, epoch, 1u, 0u, seed, 0x6F6B656Eu);
+    const int pick_random_point = (flags & 1u) != 0u, randomize_lane = (flags & 2u) != 0u, randomize_heading = (flags & 4u) != 0u;
+    /* :83  reset_idx = pick_random_point ? pickRandomResetTrackIdx() : RaceTrack::kStartingIdx (= 3, RaceTrack.h:18) */
+    const int32_t reset_idx = pick_random_point ? rand_value_from_word(words.v[0], 0, e->P - 1) : 3;
+    /* :86-101 */
+    float heading_offset = 0.0f;
+    if (pick_random_point && randomize_heading) {
+        const float kHeadingRandomizationRangeDeg = 45.0f;
+        heading_offset = (float)rand_value_from_word(words.v[1], 0, 45);
+        if (ctr % 2u == 0u) heading_offset = (heading_offset + kHeadingRandomizationRangeDeg) * -1.0f;
+        else heading_offset = heading_offset + kHeadingRandomizationRangeDeg;
+    }
+    /* :103-120 */
+    float start_pos_x, start_pos_y;
+    if (pick_random_point && randomize_lane) {
+        const float lx = e->lane_l[2 * reset_idx], ly = e->lane_l[2 * reset_idx + 1];
+        const float rx = e->lane_r[2 * reset_idx], ry = e->lane_r[2 * reset_idx + 1];
+        const float alpha = (float)rand_value_from_word(words.v[2], 10, 90) / 100.0f;
+        start_pos_x = lx * alpha + rx * (1.0f - alpha);
+        start_pos_y = ly * alpha + ry * (1.0f - alpha);
+    } else {
+        start_pos_x = e->cx[reset_idx];
+        start_pos_y = e->cy[reset_idx];
+    }
+    /* :121 */
+    agent_reset(e, i, start_pos_x, start_pos_y, e->chead[reset_idx] + heading_offset);
 }
 
 /* batch form: entry j of the call stands for the (epoch + j)-th resetAgent call of the process */
@@ -725,6 +795,75 @@ ORACLE_API void oracle_ga_set_weights(oracle_env *e, const float *in)
     memcpy(e->mlp_w, in, sizeof(float) * (size_t)e->N * OK_MLP_WEIGHTS(e->R));
 }
 
+/* genetic::normalizeAngleDeg (EvolutionaryRacer/Network.hpp:16-27).  (An infinite or NaN angle makes the reference spin
+ * forever; the bound keeps the oracle from hanging and is never reached by finite headings below 2.4e7 degrees.) */
+static float ga_normalize_angle_deg(float angle)
+{
+    int guard = 65536;
+    while (angle < 360.0f && guard-- > 0) angle += 360.0f;
+    guard = 65536;
+    while (angle >= 360.0f && guard-- > 0) angle -= 360.0f;
+    return angle;
+}
+
+/* GeneticAgent::updateAction's Sigmoid branch (EvolutionaryRacer/GeneticAgent.hpp:45-54) on the six PRE-activations:
+ * nn_output_[k] = sigmoid(z[k]) > kOutputActivationLim (0.5) holds exactly when z[k] > 0, except for 0 < z < ~6e-8 where
+ * the fp32 sigmoid rounds to 0.5 (documented deviation).  kAccelerationDelta 0.3, kSteeringDeltaLow 1,
+ * kSteeringDeltaHigh 4 (GeneticAgent.hpp:19-24). */
+static void ga_decode_outputs(const float z[6], float *throttle_delta_out, float *steering_delta_out)
+{
+    float throttle_delta = 0.0f, steering_delta = 0.0f;
+    throttle_delta += (z[0] > 0.0f) ? 0.3f : 0.0f;
+    throttle_delta += (z[1] > 0.0f) ? -0.3f : 0.0f;
+    steering_delta += (z[2] > 0.0f) ? 1.0f : 0.0f;  /* left soft  */
+    steering_delta += (z[3] > 0.0f) ? 4.0f : 0.0f;  /* left hard  */
+    steering_delta += (z[4] > 0.0f) ? -1.0f : 0.0f; /* right soft */
+    steering_delta += (z[5] > 0.0f) ? -4.0f : 0.0f; /* right hard */
+    *throttle_delta_out = throttle_delta;
+    *steering_delta_out = steering_delta;
+}
+
+/* std::discrete_distribution over the parents' scores (EvolutionaryRacer/Mating.hpp:135-137) driven by one uniform draw:
+ * weights are the (non-negative) scores; all-zero weights make the distribution uniform, as libstdc++ does. */
+static int ga_draw_parent(const float *scores, int K, float u)
+{
+    float total = 0.0f;
+    for (int k = 0; k < K; ++k) total += (scores[k] > 0.0f) ? scores[k] : 0.0f;
+    if (!(total > 0.0f)) {
+        const int k = (int)(u * (float)K);
+        return k < K ? k : K - 1;
+    }
+    const float target = u * total;
+    float running = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        running += (scores[k] > 0.0f) ? scores[k] : 0.0f;
+        if (target < running) return k;
+    }
+    return K - 1;
+}
+
+/* chooseAndMateAgents' parent choice (EvolutionaryRacer/Mating.hpp:128-152): network 0 is the best agent's clone,
+ * network 1 the best mated with itself; every further one draws first_agent, then second_agent until it differs
+ * ("Prevent self-mutation").  The mt19937 seeded from random_device is replaced by Philox draws (offspring, attempt, 3,
+ * generation); after 16 equal draws the next parent is taken so that the loop ends.  *clone_out = exact copy. */
+static void ga_choose_parents(const float *scores, int K, uint32_t seed, uint32_t offspring, uint32_t generation, int *first_out,
+                              int *second_out, int *clone_out)
+{
+    *clone_out = 0;
+    if (offspring == 0u) { *first_out = 0; *second_out = 0; *clone_out = 1; return; }
+    if (offspring == 1u || K < 2) { *first_out = 0; *second_out = 0; return; }
+    const ok_u32x4 r0 = ok_philox4x32(offspring, 0u, 3u, generation, seed, 0x6F6B656Eu);
+    const int first_agent = ga_draw_parent(scores, K, ok_u01(r0.v[0]));
+    int second_agent = -1;
+    for (uint32_t attempt = 1u; attempt <= 16u && (second_agent == -1 || second_agent == first_agent); ++attempt) {
+        const ok_u32x4 r = ok_philox4x32(offspring, attempt, 3u, generation, seed, 0x6F6B656Eu);
+        second_agent = ga_draw_parent(scores, K, ok_u01(r.v[0]));
+    }
+    if (second_agent == first_agent) second_agent = (first_agent + 1) % K;
+    *first_out = first_agent;
+    *second_out = second_agent;
+}
+
 /* GeneticAgent::updateAction (GeneticAgent.hpp:37-107) + Network::infer (Network.hpp:119-155).  Accumulation orders:
  * hidden unit u over inputs j = 0..R+1, output k over hidden units i = 0..31 (zero-padded beyond the hidden width). */
 static void ga_update_action(oracle_env *e, int a)
@@ -734,7 +873,7 @@ static void ga_update_action(oracle_env *e, int a)
     const float *w2 = w1 + (R + 2) * OK_MLP_HID_PAD;
     float h[OK_MLP_HID_PAD], z[OK_MLP_OUT];
     const float x0 = e->speed[a] / 100.0f;
-    const float x1 = ok_normalize_angle_deg(e->rot[a]) / 360.0f;
+    const float x1 = ga_normalize_angle_deg(e->rot[a]) / 360.0f;
     for (int u = 0; u < OK_MLP_HID_PAD; ++u) {
         float acc = 0.0f;
         acc = acc + x0 * w1[0 * OK_MLP_HID_PAD + u];
@@ -750,7 +889,7 @@ static void ga_update_action(oracle_env *e, int a)
         for (int i = 0; i < OK_MLP_HID_PAD; ++i) acc = acc + h[i] * w2[i * OK_MLP_OUT_PAD + k];
         z[k] = acc;
     }
-    ok_ga_decode_action(z, &e->thr[a], &e->steer[a]);
+    ga_decode_outputs(z, &e->thr[a], &e->steer[a]);
 }
 
 /* genetic_learner_sim.cpp:76-95: n x { updateAction for all; env.step() } */
@@ -809,9 +948,9 @@ ORACLE_API void oracle_ga_select_mate(oracle_env *e, uint32_t seed, uint32_t gen
     float *nw = ALLOC(float, (size_t)N * per);
     for (int o = 0; o < N; ++o) {
         const uint32_t og = agent_base + (uint32_t)o;
-        const uint32_t pair = ok_ga_parent_pair(ps, K, seed, og, generation);
-        const uint32_t first = pair & 0xFFu, second = (pair >> 8) & 0xFFu;
-        const int clone = (int)((pair >> 16) & 1u);
+        int first_i, second_i, clone;
+        ga_choose_parents(ps, K, seed, og, generation, &first_i, &second_i, &clone);
+        const uint32_t first = (uint32_t)first_i, second = (uint32_t)second_i;
         const uint32_t dom = (ps[first] > ps[second]) ? first : second; /* n1 = agent_2 on ties (Mating.hpp:59) */
         const uint32_t sub = (ps[first] > ps[second]) ? second : first;
         const float *wd = e->mlp_w + (size_t)parents[dom] * per;

@@ -82,6 +82,18 @@ extern "C"
         }
     }
 
+    // RaceTrack::getNearestDistanceToTrackBoundary / getDistanceToLaneCenter for n probe points
+    __attribute__((visibility("default"))) void
+    ref_track_queries(void *tp, const float *qx, const float *qy, int n, float *out_boundary, float *out_lane_center)
+    {
+        auto *t = static_cast<RaceTrack *>(tp);
+        for (int i = 0; i < n; ++i)
+        {
+            out_boundary[i]    = t->getNearestDistanceToTrackBoundary(Vec2d{qx[i], qy[i]});
+            out_lane_center[i] = t->getDistanceToLaneCenter(Vec2d{qx[i], qy[i]});
+        }
+    }
+
     // Drives the reference's Agent::move() n_steps times with the given per-step actions.
     // out arrays hold the state AFTER each step: x, y, rot, speed, acceleration.
     __attribute__((visibility("default"))) void ref_agent_rollout(int         mode,

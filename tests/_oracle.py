@@ -60,6 +60,8 @@ def lib():
         L.oracle_track_get.argtypes = [C.c_void_p, C.c_int, f32p]
         L.oracle_track_segments.argtypes = [C.c_void_p, f32p]
         L.oracle_nearest_track_idx.argtypes = [f32p, f32p, C.c_int, f32p, f32p, C.c_int, i32p]
+        L.oracle_boundary_distance.argtypes = [f32p, f32p, C.c_int, f32p, f32p, C.c_int, f32p]
+        L.oracle_lane_center_distance.argtypes = [f32p, f32p, f32p, f32p, C.c_int, f32p, f32p, C.c_int, f32p]
         L.oracle_env_create.restype = C.c_void_p
         L.oracle_env_create.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p]
         L.oracle_env_destroy.argtypes = [C.c_void_p]
@@ -125,6 +127,7 @@ def ref():
         L.ref_track_num_points.argtypes = [C.c_void_p]
         L.ref_track_get.argtypes = [C.c_void_p, C.c_int, f32p]
         L.ref_nearest_track_idx.argtypes = [C.c_void_p, f32p, f32p, C.c_int, i32p]
+        L.ref_track_queries.argtypes = [C.c_void_p, f32p, f32p, C.c_int, f32p, f32p]
         L.ref_agent_rollout.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, f32p, f32p, C.c_int, f32p, f32p,
                                         f32p, f32p, f32p]
         L.ref_agent_reset_probe.argtypes = [C.c_float, C.c_float, C.c_float, f32p]

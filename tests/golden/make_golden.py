@@ -4,7 +4,8 @@ reference-derived part):   python tests/golden/make_golden.py
   ref_tracks.npz      -- FROM THE REFERENCE's compiled RaceTrack.cpp (oracle/_ref): per config track P, the fp32 bit
                          hashes (sha256) of the centre line, widths, headings and the four boundary polylines, the
                          first/last 8 centre-line points, headings and boundary points, and the reference's
-                         findNearestTrackIndexBruteForce answers for 256 probe points.
+                         findNearestTrackIndexBruteForce / getNearestDistanceToTrackBoundary / getDistanceToLaneCenter
+                         answers for 256 probe points.
   ref_kinematics.npz  -- FROM THE REFERENCE's compiled Agent.cpp: Agent::move trajectories (VELOCITY and
                          ACCELERATION) under seeded actions, 400 steps each; plus the default sensor fan and the
                          Agent::reset probe.
@@ -50,7 +51,12 @@ def main():
         h = O.ref().ref_track_load(O.track_path(name).encode())
         O.ref().ref_nearest_track_idx(h, qx, qy, 256, idx)
         O.ref().ref_track_free(h)
+        bd, lc = np.zeros(256, dtype=np.float32), np.zeros(256, dtype=np.float32)
+        h = O.ref().ref_track_load(O.track_path(name).encode())
+        O.ref().ref_track_queries(h, qx, qy, 256, bd, lc)
+        O.ref().ref_track_free(h)
         out[name + "_probe_x"], out[name + "_probe_y"], out[name + "_probe_idx"] = qx, qy, idx
+        out[name + "_probe_boundary"], out[name + "_probe_lane"] = bd, lc
     np.savez_compressed(os.path.join(HERE, "ref_tracks.npz"), **out)
 
     kin = {}

@@ -38,12 +38,23 @@ def test_oracle_track_matches_reference_fixture(oracle, name):
     got = np.zeros(256, dtype=np.int32)
     O.lib().oracle_nearest_track_idx(t.x, t.y, t.P, g[name + "_probe_x"], g[name + "_probe_y"], 256, got)
     assert np.array_equal(got, g[name + "_probe_idx"])
+    # RaceTrack::getNearestDistanceToTrackBoundary / getDistanceToLaneCenter (RaceTrack.cpp:33-72)
+    bd, lc = np.zeros(256, dtype=np.float32), np.zeros(256, dtype=np.float32)
+    O.lib().oracle_boundary_distance(t.li, t.ri, t.P, g[name + "_probe_x"], g[name + "_probe_y"], 256, bd)
+    O.lib().oracle_lane_center_distance(t.x, t.y, t.wl, t.wr, t.P, g[name + "_probe_x"], g[name + "_probe_y"], 256, lc)
+    assert np.array_equal(bits(bd), bits(g[name + "_probe_boundary"]))
+    assert np.array_equal(bits(lc), bits(g[name + "_probe_lane"]))
 
 
 @pytest.mark.parametrize("name", TRACKS)
 def test_product_track_matches_reference_fixture(ok, name):
     g = np.load(os.path.join(GOLD, "ref_tracks.npz"))
-    check_track(ok.Track(name), g, name)
+    t = ok.Track(name)
+    check_track(t, g, name)
+    # the product's RaceTrack query methods (C ABI okenv_track_queries) against the reference's answers
+    bd, lc = t.queries(g[name + "_probe_x"], g[name + "_probe_y"])
+    assert np.array_equal(bits(bd), bits(g[name + "_probe_boundary"]))
+    assert np.array_equal(bits(lc), bits(g[name + "_probe_lane"]))
 
 
 @pytest.mark.parametrize("mode", [0, 1])

@@ -66,6 +66,32 @@ def test_nearest_index_equal_to_reference(oracle, name):
 
 
 @needs_ref
+@pytest.mark.parametrize("name", ["Austin", "Silverstone", "Monza", "Spa"])
+def test_track_queries_equal_to_reference(oracle, name):
+    """RaceTrack::getNearestDistanceToTrackBoundary / getDistanceToLaneCenter: oracle restatement and the product's own
+    RaceTrack (through the C ABI) against the reference's compiled RaceTrack.cpp, bit for bit, 3000 probes."""
+    import openkitchen_amd as ok
+    t = O.Track(name, "oracle")
+    rng = np.random.default_rng(2)
+    qx = rng.uniform(0, 1600, 3000).astype(np.float32)
+    qy = rng.uniform(0, 1400, 3000).astype(np.float32)
+    qx[:t.P], qy[:t.P] = t.x, t.y
+    qx[t.P:2 * t.P], qy[t.P:2 * t.P] = t.li[0::2], t.li[1::2]
+    wb, wl = np.zeros(3000, dtype=np.float32), np.zeros(3000, dtype=np.float32)
+    h = O.ref().ref_track_load(O.track_path(name).encode())
+    O.ref().ref_track_queries(h, qx, qy, 3000, wb, wl)
+    O.ref().ref_track_free(h)
+    gb, gl = np.zeros(3000, dtype=np.float32), np.zeros(3000, dtype=np.float32)
+    O.lib().oracle_boundary_distance(t.li, t.ri, t.P, qx, qy, 3000, gb)
+    O.lib().oracle_lane_center_distance(t.x, t.y, t.wl, t.wr, t.P, qx, qy, 3000, gl)
+    assert np.array_equal(gb.view(np.uint32), wb.view(np.uint32))
+    assert np.array_equal(gl.view(np.uint32), wl.view(np.uint32))
+    pb, pl = ok.Track(name).queries(qx, qy)
+    assert np.array_equal(pb.view(np.uint32), wb.view(np.uint32))
+    assert np.array_equal(pl.view(np.uint32), wl.view(np.uint32))
+
+
+@needs_ref
 @pytest.mark.parametrize("mode", [0, 1])
 def test_kinematics_bit_equal_to_reference_agent(oracle, mode):
     """Oracle kinematics in glibc-trig mode == the reference's Agent::move, bit for bit, over 3000 steps with
