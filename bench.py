@@ -421,7 +421,8 @@ def main():
             "config": {"workload": "C2: %d agents x %d rays per GPU, %s.csv (S=%d segments), Philox random actions + auto reset, "
                                    "HIP fused kinematics+raycast+collision" % (N, R, args.track, track.S),
                        "agents_per_gpu": N, "rays": R, "track": args.track, "segments": track.S,
-                       "global_agents": total_agents, "steps_per_launch": spl, "parallelism": "dp%d (agent shards, no collective)" % world,
+                       "global_agents": total_agents, "agent_base_per_rank": [r * N for r in range(world)],
+                       "steps_per_launch": spl, "parallelism": "dp%d (agent shards, no collective)" % world,
                        "grid_cell": info["grid_cell"], "lds_bytes": info["lds_bytes"]},
             "rays_per_sec": value * R,
             # what the reference's sweep would have to evaluate for the same result: every ray against all S segments

@@ -76,5 +76,31 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+APPS_DIR = os.path.join(CSRC, "apps")
+BIN_DIR = os.path.join(PKG_DIR, "bin")
+APPS = ["genetic_learner_sim", "q_racer_sim"]
+
+
+def build_apps(verbose=False):
+    """Compiles the two applications the north star names (openkitchen_amd/csrc/apps/: the EvolutionaryRacer and the
+    Q_Learning episode loops over the C ABI) with g++ against include/okenv.h and links them to libokenv.so.  Returns the
+    paths of the executables (openkitchen_amd/bin/)."""
+    build(verbose=verbose)
+    os.makedirs(BIN_DIR, exist_ok=True)
+    out = []
+    for app in APPS:
+        src, exe = os.path.join(APPS_DIR, app + ".cpp"), os.path.join(BIN_DIR, app)
+        if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(LIB_PATH)):
+            cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", exe, src, "-L", PKG_DIR, "-lokenv",
+                   "-Wl,-rpath,$ORIGIN/.."]  # finds libokenv.so next to bin/, wherever the tree is
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True, cwd=ROOT)
+        out.append(exe)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--apps" in sys.argv:
+        print(build_apps(verbose=True))

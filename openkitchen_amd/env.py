@@ -285,6 +285,14 @@ class BatchedEnvironment:
         capi.check(self._L.okenv_ga_scores(self._h, capi.ptr(out)), self._h)
         return out
 
+    def ga_scores_into(self, device_tensor):
+        """assignScores straight into a float32 CUDA tensor of N elements (device-to-device, on this handle's stream): the
+        fitness vector never visits the host on its way into the per-generation all-gather."""
+        assert device_tensor.is_cuda and device_tensor.is_contiguous() and device_tensor.numel() == self.N
+        assert str(device_tensor.dtype) == "torch.float32"
+        capi.check(self._L.okenv_ga_scores(self._h, C.c_void_p(device_tensor.data_ptr())), self._h)
+        return device_tensor
+
     def ga_select_mate(self, seed, generation, agent_base=0):
         parents = np.zeros(5, dtype=np.int32)
         capi.check(self._L.okenv_ga_select_mate(self._h, int(seed), int(generation), int(agent_base), capi.ptr(parents)), self._h)

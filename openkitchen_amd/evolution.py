@@ -26,6 +26,7 @@ class EvolutionaryRacer:
         env.policy_mlp_create(hidden, seed, agent_base)
         self.start = (float(track.x[3]), float(track.y[3]), float(track.heading[0]))  # genetic_learner_sim.cpp:34-36
         self.history = []
+        self._fitness = None  # device tensor the scores are written into (GPU runs)
 
     def rollout(self):
         """Reset everybody to the start line and drive until every agent has crashed or timed out."""
@@ -45,16 +46,23 @@ class EvolutionaryRacer:
         t0 = time.perf_counter()
         steps = self.rollout()
         t1 = time.perf_counter()
-        scores = self.env.ga_scores()  # assignScores
-        local = torch.as_tensor(scores, dtype=torch.float32, device=self.device if self.device is not None else "cpu")
+        on_gpu = self.device is not None and str(self.device).startswith("cuda")
+        if on_gpu:
+            # assignScores into a device tensor, all-gather from there (RCCL reads device memory): no host hop on the data path
+            if self._fitness is None:
+                self._fitness = torch.empty(self.env.N, dtype=torch.float32, device=self.device)
+            local = self.env.ga_scores_into(self._fitness)
+            self.env.sync()  # the copy ran on the environment's stream; the collective runs on torch's
+        else:
+            local = torch.as_tensor(self.env.ga_scores(), dtype=torch.float32)
         colony = sharding.all_gather_fitness(local)  # [world, N]: global colony statistics (showColonyScore)
         parents = self.env.ga_select_mate(self.seed, self.generation, self.agent_base)  # chooseAndMateAgents
         self.env.sync()
         t2 = time.perf_counter()
+        stats = torch.stack([local.max(), local.mean(), colony.max(), colony.mean()]).tolist()  # four scalars leave the device
         rec = {"generation": self.generation, "steps": steps, "rollout_s": t1 - t0, "select_mate_s": t2 - t1,
-               "island_best": float(scores.max()), "island_mean": float(scores.mean()),
-               "colony_best": float(colony.max().item()), "colony_mean": float(colony.mean().item()),
-               "parents": parents.tolist()}
+               "island_best": stats[0], "island_mean": stats[1], "colony_best": stats[2], "colony_mean": stats[3],
+               "parents": [int(v) for v in parents]}
         self.history.append(rec)
         self.generation += 1
         return rec

@@ -1085,6 +1085,10 @@ ORACLE_API void oracle_q_get_table(const oracle_env *e, float *out)
 {
     memcpy(out, e->q_table, sizeof(float) * (size_t)e->N * Q_STATES * Q_ACTIONS);
 }
+ORACLE_API void oracle_q_set_table(oracle_env *e, const float *in)
+{
+    memcpy(e->q_table, in, sizeof(float) * (size_t)e->N * Q_STATES * Q_ACTIONS);
+}
 ORACLE_API void oracle_q_get_state(const oracle_env *e, int32_t *state, int32_t *action, int32_t *prev)
 {
     memcpy(state, e->q_state, 4 * (size_t)e->N); memcpy(action, e->q_action, 4 * (size_t)e->N); memcpy(prev, e->q_prev, 4 * (size_t)e->N);

@@ -105,6 +105,7 @@ def lib():
         L.oracle_q_begin_episode.argtypes = [C.c_void_p, C.c_int]
         L.oracle_rollout_q.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32]
         L.oracle_q_get_table.argtypes = [C.c_void_p, f32p]
+        L.oracle_q_set_table.argtypes = [C.c_void_p, f32p]
         L.oracle_q_get_state.argtypes = [C.c_void_p, i32p, i32p, i32p]
         _lib = L
     return _lib

@@ -96,3 +96,94 @@ def test_two_rank_gloo_population_matches_unsharded(oracle, tmp_path):
     want = np.zeros(24, dtype=np.int32)
     oracle.lib().oracle_nearest_track_idx(t.x, t.y, t.P, s["pos_x"], s["pos_y"], 24, want)
     assert np.array_equal(fit.reshape(-1).astype(np.int32), want)
+
+
+GA_WORKER = textwrap.dedent('''
+    import json, os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    import _oracle as O
+    from openkitchen_amd.evolution import EvolutionaryRacer
+
+    class OracleIsland:
+        """Test-only engine with the BatchedEnvironment methods EvolutionaryRacer uses (the product's engine needs a GPU)."""
+        def __init__(self, track, n, rays):
+            self.N = n
+            self.env = O.OracleEnv(track.segments, n, rays, O.default_ray_fan(rays), (track.x, track.y, track.heading))
+            self.ga = None
+        def set(self, field, arr): self.env.set(field, arr)
+        def policy_mlp_create(self, hidden, seed, agent_base): self.ga = O.OracleGA(self.env, hidden, seed, agent_base)
+        def reset_all(self, x, y, rot): self.ga.reset_all(x, y, rot)
+        def step(self, n): self.env.step(n)
+        def rollout_policy(self, n): self.ga.rollout_policy(n)
+        def alive_count(self): return self.ga.alive_count()
+        def ga_scores(self): return self.ga.scores()
+        def ga_select_mate(self, seed, generation, agent_base): return self.ga.select_mate(seed, generation, agent_base)
+        def sync(self): pass
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    track = O.Track("Monza")
+    N = 20
+    island = OracleIsland(track, N, 8)
+    ga = EvolutionaryRacer(island, track, hidden=30, seed=500 + rank, agent_base=rank * N, max_steps=260, steps_per_launch=65, device=None)
+    recs = [ga.run_generation() for _ in range(2)]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, recs)
+    if rank == 0:
+        json.dump(gathered, open(%(out)r, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def test_two_rank_generation_loop_all_gathers_fitness(oracle, tmp_path):
+    """The product's EvolutionaryRacer.run_generation (openkitchen_amd/evolution.py) on two gloo ranks, one island population
+    per rank: island statistics equal a single-process replay of each island, and colony_best / colony_mean -- computed from
+    the all-gathered fitness -- equal the statistics of the two islands' scores taken together, on both ranks."""
+    import json
+    out = str(tmp_path / "ga.json")
+    script = tmp_path / "ga_worker.py"
+    script.write_text(GA_WORKER % {"root": ROOT, "out": out})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                    "--master-port", str(free_port()), str(script)], check=True, env=env, timeout=900, cwd=ROOT)
+    ranks = json.load(open(out))
+    assert len(ranks) == 2 and all(len(r) == 2 for r in ranks)
+    # single-process replay of both islands (genetic_learner_sim.cpp:47-96 on the oracle)
+    t = oracle.Track("Monza")
+    N = 20
+    start = (float(t.x[3]), float(t.y[3]), float(t.heading[0]))
+    scores = {}
+    for rank in range(2):
+        env1 = oracle.OracleEnv(t.segments, N, 8, oracle.default_ray_fan(8), (t.x, t.y, t.heading))
+        env1.set(oracle.F_MODE, np.ones(N, dtype=np.uint8))
+        ga = oracle.OracleGA(env1, 30, 500 + rank, rank * N)
+        for g in range(2):
+            ga.reset_all(*start)
+            env1.step(1)
+            steps = 1
+            while steps < 260:
+                n = min(65, 260 - steps)
+                ga.rollout_policy(n)
+                steps += n
+                if ga.alive_count() == 0:
+                    break
+            scores[(rank, g)] = ga.scores()
+            rec = ranks[rank][g]
+            assert rec["steps"] == steps
+            assert rec["island_best"] == float(scores[(rank, g)].max())
+            assert rec["island_mean"] == float(np.float32(torch_mean(scores[(rank, g)])))
+            assert rec["parents"] == [int(v) for v in ga.select_mate(500 + rank, g, rank * N)]
+    for g in range(2):
+        both = np.stack([scores[(0, g)], scores[(1, g)]])
+        for rank in range(2):
+            assert ranks[rank][g]["colony_best"] == float(both.max())
+            assert ranks[rank][g]["colony_mean"] == float(np.float32(torch_mean(both)))
+
+
+def torch_mean(a):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).mean().item()
