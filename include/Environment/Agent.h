@@ -69,7 +69,7 @@ class OKENV_CLASS Agent
     float   radius_{9.0F};        // drawing only: the crash test is purely lidar-based
     float   sensor_offset_{0.0F}; // lidar origin ahead of the centre, along the heading [px]
     int16_t id_{};
-    int     color_[4]{80, 80, 80, 255};
+    AgentColor color_{}; // RGBA, dark gray
 
     bool has_raycast_sensor_{true};
     bool manual_control_enabled_{true};

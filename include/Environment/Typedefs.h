@@ -5,6 +5,8 @@
 // GOX_ASSERT).  Written for this project; nothing here touches a GPU.
 #pragma once
 
+#include <cstddef>
+
 #include <cmath>
 #include <exception>
 #include <math.h>
@@ -50,6 +52,34 @@ struct Vec2d
     Vec2d operator*(const float k) const { return {x * k, y * k}; }
     Vec2d operator/(const Vec2d &o) const { return {x / o.x, y / o.y}; }
     Vec2d operator/(const float k) const { return {x / k, y / k}; }
+};
+
+// ---- the drawing library's vocabulary the callers use, headless (there is no window on this path) ----------------
+// The applications written against the legacy Environment header (AutoEncoder/collect_data_racetrack/Environment.hpp:
+// RLRacers/Q_Learning/q_racer_sim.cpp, QAgent.hpp) name positions `raylib::Vector2` and colours by raylib's constants.
+namespace raylib
+{
+using Vector2 = ::Vec2d;
+}
+struct Color
+{
+    unsigned char r, g, b, a;
+};
+constexpr Color WHITE{255, 255, 255, 255}, BLACK{0, 0, 0, 255}, RED{230, 41, 55, 255}, GREEN{0, 228, 48, 255},
+    BLUE{0, 121, 241, 255}, YELLOW{253, 249, 0, 255};
+
+// Agent::color_: `int color_[4]` in the current reference header (Environment/Agent.h:63), a raylib Color in the legacy
+// one (`greedy_agent->color_ = BLUE`, q_racer_sim.cpp:109).  Indexable like the former, assignable from the latter.
+struct AgentColor
+{
+    int rgba[4]{80, 80, 80, 255}; // dark gray
+    int       &operator[](const size_t i) { return rgba[i]; }
+    const int &operator[](const size_t i) const { return rgba[i]; }
+    AgentColor &operator=(const Color &c)
+    {
+        rgba[0] = c.r, rgba[1] = c.g, rgba[2] = c.b, rgba[3] = c.a;
+        return *this;
+    }
 };
 
 struct Extent2d

@@ -18,12 +18,7 @@ class CollisionChecker;
 // YELLOW)`, RLRacers/PPO/ppo_sim.cpp:38-43) and draw their random numbers from the same library
 // (`GetRandomValue(lo, hi)`, inclusive).  Without a window the former does nothing; the latter is served by the
 // generator behind Environment::resetAgent, so Environment::seedRandom makes such callers reproducible.
-struct Color
-{
-    unsigned char r, g, b, a;
-};
-constexpr Color WHITE{255, 255, 255, 255}, BLACK{0, 0, 0, 255}, RED{230, 41, 55, 255}, GREEN{0, 228, 48, 255},
-    BLUE{0, 121, 241, 255}, YELLOW{253, 249, 0, 255};
+// (Color and its constants: Typedefs.h)
 inline void DrawText(const char * /*text*/, int /*x*/, int /*y*/, int /*font_size*/, Color /*color*/) {}
 OKENV_CLASS int GetRandomValue(int min, int max);
 

@@ -85,7 +85,8 @@ enum okenv_field {
     OKENV_F_TRACK_IDX = 21,      /* i32  prev_track_idx_ (main_eigen.cpp:84); PROGRESS reward only, else 0 */
     OKENV_F_EPISODE_STEPS = 22,  /* u32  updates since the episode began                      */
     OKENV_F_EPISODE_RETURN = 23, /* f32  fitness at the end of the last finished episode     */
-    OKENV_F_COUNT_ALL = 24
+    OKENV_F_PREV_CRASHED = 24,   /* u8   crashed_ as the last okenv_tracker_update / _begin saw it (detects re-placed agents) */
+    OKENV_F_COUNT_ALL = 25
 };
 
 /* Struct-of-pointers form of the per-agent state, for one-call upload/download by the C++ facade.

@@ -24,9 +24,9 @@ FIELD_NAMES = ["pos_x", "pos_y", "rot", "speed", "acc", "thr", "steer", "mode", 
 FIELD_DTYPE = [np.float32] * 7 + [np.uint8] * 3 + [np.uint32, np.float32, np.float32, np.uint8] + [np.float32] * 5
 PER_RAY = {F_HIT_X, F_HIT_Y, F_REL_X, F_REL_Y, F_DIST}
 # rollout bookkeeping fields (exist after okenv_tracker_create)
-F_REWARD, F_FITNESS, F_TRACK_IDX, F_EPISODE_STEPS, F_EPISODE_RETURN = range(19, 24)
-FIELD_NAMES += ["reward", "fitness", "track_idx", "episode_steps", "episode_return"]
-FIELD_DTYPE += [np.float32, np.float32, np.int32, np.uint32, np.float32]
+F_REWARD, F_FITNESS, F_TRACK_IDX, F_EPISODE_STEPS, F_EPISODE_RETURN, F_PREV_CRASHED = range(19, 25)
+FIELD_NAMES += ["reward", "fitness", "track_idx", "episode_steps", "episode_return", "prev_crashed"]
+FIELD_DTYPE += [np.float32, np.float32, np.int32, np.uint32, np.float32, np.uint8]
 REWARD_STEP, REWARD_PROGRESS = 0, 1
 
 # every symbol include/okenv.h declares (tests/test_capi_symbols.py checks the library exports them all)

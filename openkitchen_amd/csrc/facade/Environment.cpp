@@ -95,9 +95,40 @@ class CollisionChecker::Impl
         recs_.assign(static_cast<size_t>(n_), okenv_agent_record{});
         hits_.assign(static_cast<size_t>(n_) * r_ * 2U, 0.F);
         rays_.assign(static_cast<size_t>(n_) * r_, Ray_{0.F, 0.F, 0.F, 0.F, 0.F, true});
+        fan_ = agents[0]->sensor_ray_angles_;
+        // Step trace for record / replay checks: OKENV_TRACE_FILE=<path> makes every exchange append what went in and what
+        // came out (tests/test_reference_binding_dropin.py replays it on the CPU oracle); OKENV_TRACE_STEPS bounds the file.
+        if (const char *path = std::getenv("OKENV_TRACE_FILE"))
+        {
+            trace_ = std::fopen(path, "ab");
+            if (const char *lim = std::getenv("OKENV_TRACE_STEPS"))
+                trace_left_ = std::atol(lim);
+        }
     }
 
-    ~Impl() { okenv_destroy(h_); }
+    ~Impl()
+    {
+        if (trace_)
+            std::fclose(trace_);
+        okenv_destroy(h_);
+    }
+
+    // One trace record: {magic, n, r, flags} {sensor_offset} fan[r] in[n] out[n] hits[n * r * 2]
+    void trace(const std::vector<okenv_agent_record> &in, const uint32_t flags)
+    {
+        if (!trace_ || trace_left_ <= 0)
+            return;
+        --trace_left_;
+        const uint32_t head[4] = {0x4F4B5452U /* "OKTR" */, static_cast<uint32_t>(n_), static_cast<uint32_t>(r_), flags};
+        const float    off     = agents_[0]->sensor_offset_;
+        std::fwrite(head, 4, 4, trace_);
+        std::fwrite(&off, 4, 1, trace_);
+        std::fwrite(fan_.data(), 4, fan_.size(), trace_);
+        std::fwrite(in.data(), sizeof(okenv_agent_record), in.size(), trace_);
+        std::fwrite(recs_.data(), sizeof(okenv_agent_record), recs_.size(), trace_);
+        std::fwrite(hits_.data(), 4, hits_.size(), trace_);
+        std::fflush(trace_);
+    }
 
     // Agent objects -> packed records -> device, one step (or only the collision pass), and back: two PCIe copies
     // per call (okenv_step_packed).  The four `disp_*` arrays (optional) carry Environment's DisplacementStats.
@@ -127,11 +158,25 @@ class CollisionChecker::Impl
                 r.disp_timed_out = disp_to[i];
             }
         }
+        // The reference reads sensor_offset_ and sensor_ray_angles_ per agent on every call (CollisionChecker.cu:113-128); the
+        // device keeps ONE fan and ONE offset for the population, so anything else must not pass silently.
+        for (int i = 0; i < n_; ++i)
+        {
+            if (agents[i]->sensor_offset_ != agents[0]->sensor_offset_ || agents[i]->sensor_ray_angles_ != fan_)
+            {
+                std::cerr << "okenv: agent " << i << " has its own sensor_offset_ / sensor_ray_angles_ (or the fan changed after the "
+                          << "CollisionChecker was built): one fan and one offset per Environment are supported" << std::endl;
+                std::terminate();
+            }
+        }
         if (okenv_set_sensor_offset(h_, agents[0]->sensor_offset_) != OKENV_OK)
             die("okenv_set_sensor_offset", h_);
         const uint32_t flags = (with_stats ? OKENV_PACKED_WITH_STATS : 0U) | (collide_only ? OKENV_PACKED_COLLIDE_ONLY : 0U);
+        if (trace_ && trace_left_ > 0)
+            trace_in_ = recs_;
         if (okenv_step_packed(h_, recs_.data(), recs_.data(), hits_.data(), flags) != OKENV_OK)
             die("okenv_step_packed", h_);
+        trace(trace_in_, flags);
         for (int i = 0; i < n_; ++i)
         {
             Agent                    *a = agents[i];
@@ -192,8 +237,10 @@ class CollisionChecker::Impl
     okenv_t              h_{nullptr};
     std::vector<Agent *> agents_;
     int                  n_{0}, r_{0};
-    std::vector<okenv_agent_record> recs_;
-    std::vector<float>              hits_;
+    std::vector<okenv_agent_record> recs_, trace_in_;
+    std::vector<float>              hits_, fan_;
+    std::FILE                      *trace_{nullptr};
+    long                            trace_left_{100000};
     std::vector<Ray_>               rays_;
     bool                  rays_valid_{false};
 };

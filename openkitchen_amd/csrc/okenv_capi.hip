@@ -168,6 +168,7 @@ FieldDesc fieldOf(okenv *h, const int f)
     case OKENV_F_TRACK_IDX: return {h->tracker.prev_idx, h->tracker.prev_idx ? 4 * N : 0};
     case OKENV_F_EPISODE_STEPS: return {h->tracker.ep_steps, h->tracker.ep_steps ? 4 * N : 0};
     case OKENV_F_EPISODE_RETURN: return {h->tracker.ep_return, h->tracker.ep_return ? 4 * N : 0};
+    case OKENV_F_PREV_CRASHED: return {h->tracker.prev_crashed, h->tracker.prev_crashed ? N : 0};
     default: return {nullptr, 0};
     }
 }
@@ -1027,6 +1028,8 @@ extern "C"
             return fail(h, OKENV_ERR_STATE, "okenv_nearest_track_idx: call okenv_set_centerline first");
         OK_HIP(h, hipSetDevice(h->device));
         const bool agents = (qx == nullptr);
+        if (!agents && !qy) // every argument is validated before anything is allocated
+            return fail(h, OKENV_ERR_INVALID, "okenv_nearest_track_idx: qy is NULL");
         if (agents)
             n = h->N;
         if (n <= 0)
@@ -1037,9 +1040,11 @@ extern "C"
         const float *dqx = h->st.pos_x, *dqy = h->st.pos_y;
         if (!agents)
         {
-            if (!qy)
-                return fail(h, OKENV_ERR_INVALID, "okenv_nearest_track_idx: qy is NULL");
-            OK_HIP(h, hipMallocAsync(reinterpret_cast<void **>(&dq), 8U * n, h->stream));
+            if (hipMallocAsync(reinterpret_cast<void **>(&dq), 8U * n, h->stream) != hipSuccess)
+            {
+                (void)hipFreeAsync(dout, h->stream);
+                return fail(h, OKENV_ERR_HIP, "okenv_nearest_track_idx: out of device memory");
+            }
             OK_HIP(h, hipMemcpyAsync(dq, qx, 4U * n, hipMemcpyDefault, h->stream));
             OK_HIP(h, hipMemcpyAsync(dq + n, qy, 4U * n, hipMemcpyDefault, h->stream));
             dqx = dq;

@@ -44,7 +44,9 @@ class VectorEnvironment:
               # DisplacementStats (the standstill bookkeeping, Environment.h:17-27)
               "disp_ctr": capi.F_DISP_CTR, "disp_x": capi.F_DISP_X, "disp_y": capi.F_DISP_Y, "disp_timed_out": capi.F_DISP_TO}
     TRACKER_FIELDS = {"reward": capi.F_REWARD, "fitness": capi.F_FITNESS, "track_idx": capi.F_TRACK_IDX,
-                      "episode_steps": capi.F_EPISODE_STEPS, "episode_return": capi.F_EPISODE_RETURN}
+                      "episode_steps": capi.F_EPISODE_STEPS, "episode_return": capi.F_EPISODE_RETURN,
+                      # the tracker's memory of crashed_ at its last update: part of the state capture() saves and restores
+                      "prev_crashed": capi.F_PREV_CRASHED}
     SENSOR_RANGE = 200.0  # Agent::kSensorRange (Environment/Agent.h:10)
 
     def __init__(self, race_track_path, num_envs, num_rays=15, ray_angles_deg=None, device=0,

@@ -124,8 +124,13 @@ def test_graph_replay_matches_eager_and_oracle(gpu, oracle):
             orc.tracker_update()
 
     before = venv.pos_x.clone()
-    graph = venv.capture(body, warmup=3)  # warm-up iterations run, then everything they changed is restored
+    prev_before = venv.prev_crashed.clone()
+    # many warm-up iterations, so that agents do crash during them: everything they changed is restored afterwards,
+    # including the tracker's memory of crashed_ (an agent crashed on the last warm-up step must not be taken for a
+    # re-placed one by the first update after the capture: the oracle comparison below would see its fitness zeroed)
+    graph = venv.capture(body, warmup=40)
     assert venv.env.step_count == orc.step_count == 1 and torch.equal(venv.pos_x, before)
+    assert torch.equal(venv.prev_crashed, prev_before)
     it.zero_()
     restarts = 0
     for chunk in range(6):
