@@ -56,6 +56,7 @@ struct okenv
     uint32_t    reset_flags{0}, reset_seed{0}, reset_agent_base{0}; // okenv_set_auto_reset
     // packed host exchange (okenv_step_packed): pinned host staging + device records, allocated on first use
     void       *h_stage{nullptr};
+    void       *h_stage_device{nullptr}; // the same buffer as the device sees it (mapped host memory)
     void       *d_stage{nullptr};
     OkTracker   tracker{};
     int         tracker_kind{-1};
@@ -339,6 +340,8 @@ int launchStep(okenv *h, const OkStepParams &p)
                                    h->phase1_range);
             else if (policy == kPolicyMlp)
                 hipLaunchKernelGGL(okStepCoopKernel<kPolicyMlp>, grid, block, lds, h->stream, p, off, h->phase1_range);
+            else if (p.rec_in != nullptr)
+                hipLaunchKernelGGL((okStepCoopKernel<kPolicyNone, true>), grid, block, lds, h->stream, p, off, h->phase1_range);
             else
                 hipLaunchKernelGGL(okStepCoopKernel<kPolicyNone>, grid, block, lds, h->stream, p, off, h->phase1_range);
         }
@@ -475,6 +478,8 @@ extern "C"
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_plain));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyMlp>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyQ>),
@@ -518,8 +523,10 @@ extern "C"
         const long total_lanes = static_cast<long>(num_agents) * h->G;
         long       per_block   = (total_lanes + 255) / 256;
         per_block              = ((per_block + 63) / 64) * 64;
-        if (per_block < 64)
-            per_block = 64;
+        // at least four waves per workgroup: with a handful of agents the launch is dominated by staging the ~70-90 KB track
+        // image into LDS, which a single wave does four times slower (waves without an agent leave right after it)
+        if (per_block < 256)
+            per_block = 256;
         if (per_block > 1024)
             per_block = 1024;
         if (const char *env_bt = std::getenv("OKENV_BLOCK_THREADS"))
@@ -929,16 +936,56 @@ extern "C"
         const size_t out_off   = (rec_bytes + 255U) & ~static_cast<size_t>(255U); // [ in records | out records | hits ]
         const size_t hit_off   = 2U * out_off;
         if (!h->h_stage)
-        {
-            OK_HIP(h, hipHostMalloc(&h->h_stage, hit_off + hit_bytes, hipHostMallocDefault));
+        { // both buffers are committed together: a failed second allocation must not leave a half-initialised pair behind
+            void *pinned = nullptr, *mapped = nullptr;
+            OK_HIP(h, hipHostMalloc(&pinned, hit_off + hit_bytes, hipHostMallocMapped));
             uint8_t *d = nullptr;
-            const int rc = devAlloc(h, &d, hit_off + hit_bytes);
-            if (rc != OKENV_OK)
-                return rc;
-            h->d_stage = d;
+            if (hipHostGetDevicePointer(&mapped, pinned, 0) != hipSuccess || devAlloc(h, &d, hit_off + hit_bytes) != OKENV_OK)
+            {
+                (void)hipHostFree(pinned);
+                return fail(h, OKENV_ERR_HIP, "okenv_step_packed: cannot allocate the exchange buffers");
+            }
+            h->h_stage        = pinned;
+            h->h_stage_device = mapped;
+            h->d_stage        = d;
         }
         uint8_t *hs = static_cast<uint8_t *>(h->h_stage), *ds = static_cast<uint8_t *>(h->d_stage);
         std::memcpy(hs, in, rec_bytes);
+        if (h->grid_mode == kGridLds && h->coop)
+        { // ONE kernel: it reads the records from, and writes records and sensor_hits_ to, the mapped host buffer
+            uint8_t     *hm = static_cast<uint8_t *>(h->h_stage_device);
+            OkStepParams p  = baseParams(h);
+            p.rec_in         = reinterpret_cast<const okenv_agent_record *>(hm);
+            p.rec_out        = reinterpret_cast<okenv_agent_record *>(hm + out_off);
+            p.hits_xy_out    = reinterpret_cast<float *>(hm + hit_off);
+            p.rec_with_stats = (flags & OKENV_PACKED_WITH_STATS) ? 1 : 0;
+            if (flags & OKENV_PACKED_COLLIDE_ONLY)
+            {
+                p.do_move     = 0;
+                p.reset_flags = 0;
+            }
+            const int rc = launchStep(h, p);
+            if (rc != OKENV_OK)
+                return rc;
+            if ((flags & OKENV_PACKED_COLLIDE_ONLY) == 0U)
+                advanceStepCount(h, 1);
+            OK_HIP(h, hipStreamSynchronize(h->stream));
+            const okenv_agent_record *src = reinterpret_cast<const okenv_agent_record *>(hs + out_off);
+            for (size_t i = 0; i < N; ++i)
+            {
+                okenv_agent_record r = src[i];
+                if ((flags & OKENV_PACKED_WITH_STATS) == 0U)
+                { // the caller's DisplacementStats members stay as they were (`out` may alias `in`: read before writing)
+                    r.disp_x         = in[i].disp_x;
+                    r.disp_y         = in[i].disp_y;
+                    r.disp_ctr       = in[i].disp_ctr;
+                    r.disp_timed_out = in[i].disp_timed_out;
+                }
+                out[i] = r;
+            }
+            std::memcpy(sensor_hits_xy, hs + hit_off, hit_bytes);
+            return OKENV_OK;
+        }
         OK_HIP(h, hipMemcpyAsync(ds, hs, rec_bytes, hipMemcpyHostToDevice, h->stream));
         const unsigned blocks_n = static_cast<unsigned>((N + 255U) / 256U);
         hipLaunchKernelGGL(okUnpackRecordsKernel, dim3(blocks_n), dim3(256), 0, h->stream, h->st,

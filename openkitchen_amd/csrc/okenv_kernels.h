@@ -98,6 +98,13 @@ struct OkStepParams
     const uint16_t *cl_start, *cl_idx;
     int      q_ray[5];
     float    q_epsilon;
+    // Packed host exchange (okenv_step_packed, the C++ facade's Environment::step): when set, the step kernel takes the
+    // agents' state from `rec_in` and leaves state and sensor_hits_ (x, y pairs) in `rec_out` / `hits_xy_out`, all three in
+    // host memory mapped into the device, so that a facade step is ONE kernel with no staging copies around it.
+    const okenv_agent_record *rec_in;
+    okenv_agent_record       *rec_out;
+    float                    *hits_xy_out;
+    int                       rec_with_stats; // DisplacementStats travel in the records (else the device keeps its own)
 };
 
 constexpr uint32_t kAutoResetOn = 0x80000000U;
@@ -322,7 +329,8 @@ __device__ __forceinline__ void okAgentPreStep(const OkStepParams &p,
                                                const float         ray_deg = 0.F,
                                                float              *ray_sn  = nullptr,
                                                float              *ray_cs  = nullptr,
-                                               const ok_random_action *drawn = nullptr)
+                                               const bool          have_drawn = false,
+                                               const ok_random_action drawn = ok_random_action{}) // by value: a pointer here put it on the stack
 {
     if ((p.reset_flags & kAutoResetOn) != 0U && r.crashed)
     {
@@ -344,7 +352,7 @@ __device__ __forceinline__ void okAgentPreStep(const OkStepParams &p,
     {
         // the caller may have drawn this step's action already (okStepCoopKernel draws a block of steps at a time)
         const ok_random_action ra =
-            drawn != nullptr ? *drawn : ok_draw_random_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s));
+            have_drawn ? drawn : ok_draw_random_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s));
         if (r.crashed)
         {
             // Agent::reset (Agent.cpp:123-135); DisplacementStats deliberately untouched
@@ -431,7 +439,9 @@ __device__ __forceinline__ float okRayEpilogue(const OkDeviceState &st,
                                                const float          oy,
                                                const float          sr,
                                                const float          cr,
-                                               float               &dist_out)
+                                               float               &dist_out,
+                                               float               *rel_x_out = nullptr,
+                                               float               *rel_y_out = nullptr)
 {
     const float xt = hx - ox;
     const float yt = hy - oy;
@@ -440,6 +450,11 @@ __device__ __forceinline__ float okRayEpilogue(const OkDeviceState &st,
     const float n2 = rx * rx + ry * ry;
     st.rel_x[k]    = rx;
     st.rel_y[k]    = ry;
+    if (rel_x_out != nullptr)
+    {
+        *rel_x_out = rx;
+        *rel_y_out = ry;
+    }
     dist_out       = __builtin_sqrtf(n2);
     st.dist[k]     = dist_out;
     return n2;
@@ -644,7 +659,7 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
 #endif
 constexpr int kMaxSplit = OKENV_MAX_SPLIT; // intervals a pending ray is cut into at most
 
-template <int kPolicy>
+template <int kPolicy, bool kPacked = false>
 __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, const uint32_t off_coop, const float phase1_range)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
@@ -688,6 +703,28 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
     const long k        = static_cast<long>(a) * p.R + (ray_ok ? r : 0);
     const float ray_deg = p.ray_deg[ray_ok ? r : 0];
     OkAgentRegs ag      = okLoadAgent(p.st, a);
+    if (kPacked)
+    { // the caller's Agent objects, as records in mapped host memory
+        const okenv_agent_record rc = p.rec_in[a];
+        ag.pos_x                    = rc.pos_x;
+        ag.pos_y                    = rc.pos_y;
+        ag.rot                      = rc.rot;
+        ag.speed                    = rc.speed;
+        ag.acc                      = rc.acc;
+        ag.thr                      = rc.throttle;
+        ag.steer                    = rc.steer;
+        ag.mode                     = rc.mode;
+        ag.crashed                  = rc.crashed != 0;
+        ag.timed_out                = rc.timed_out != 0;
+        if (p.rec_with_stats)
+        {
+            ag.disp_x   = rc.disp_x;
+            ag.disp_y   = rc.disp_y;
+            ag.disp_ctr = rc.disp_ctr;
+            ag.disp_to  = rc.disp_timed_out != 0;
+        }
+    }
+    float       last_rel_x = 0.F, last_rel_y = 0.F; // kPacked: sensor_hits_ of the last step
     float       last_dist = (kPolicy != kPolicyNone && ray_ok) ? p.st.dist[k] : 0.F;
     int         q_state = 0, q_action = 0, q_prev = 0;
     float      *q_row0 = nullptr; // this agent's table
@@ -730,7 +767,10 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
 #define OK_WPROF(o)
 #endif
     ok_random_action ra_blk{}; // bench driver: this lane's share of the current block of drawn actions
-    for (int s = 0; s < p.n_steps; ++s)
+    // waves without a single agent (small populations get workgroups of at least 256 lanes so that the image is staged
+    // quickly) have nothing to step
+    const int n_steps = (__ballot(agent_ok) != 0ULL) ? p.n_steps : 0;
+    for (int s = 0; s < n_steps; ++s)
     {
 #if OKENV_PRIO == 2
         // A launch ends with its slowest wave, and a wave is slow for many steps in a row (its agent sits where rays are long).
@@ -763,8 +803,8 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
         // Bench driver (kActionsPhiloxReset): an action depends on (seed, agent, step) only, so lane r of the agent's group
         // draws the action of step s_blk + r and one Philox evaluation serves G steps; each step then fetches its own
         // (same draws, same bits as one evaluation per step).
-        ok_random_action        ra_now{};
-        const ok_random_action *drawn = nullptr;
+        ok_random_action ra_now{};
+        bool             have_drawn = false;
         if (kPolicy == kPolicyNone && p.action_source == kActionsPhiloxReset)
         {
             const int idx = s & (G - 1);
@@ -782,11 +822,11 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
                 ra_now.steer      = __shfl(ra_blk.steer, idx, G);
                 ra_now.reset_word = static_cast<uint32_t>(__shfl(static_cast<int>(ra_blk.reset_word), idx, G));
             }
-            drawn = &ra_now;
+            have_drawn = true;
         }
         float sr, cr;
         float rdx = 1.F, rdy = 0.F;
-        okAgentPreStep(p, ag, a, s, sr, cr, ray_deg, &rdy, &rdx, drawn);
+        okAgentPreStep(p, ag, a, s, sr, cr, ray_deg, &rdy, &rdx, have_drawn, ra_now);
         const float ox     = ag.pos_x + p.sensor_offset * cr;
         const float oy     = ag.pos_y + p.sensor_offset * sr;
         const bool  casts  = ray_ok && !ag.crashed;
@@ -893,7 +933,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
                 hx = p.st.hit_x[k];
                 hy = p.st.hit_y[k];
             }
-            min_d2 = okRayEpilogue(p.st, k, hx, hy, ox, oy, sr, cr, last_dist);
+            min_d2 = okRayEpilogue(p.st, k, hx, hy, ox, oy, sr, cr, last_dist, kPacked ? &last_rel_x : nullptr, kPacked ? &last_rel_y : nullptr);
             min_d2 = (min_d2 < OK_SENSOR_RANGE * OK_SENSOR_RANGE) ? min_d2 : OK_SENSOR_RANGE * OK_SENSOR_RANGE;
         }
         min_d2 = okGroupMin(min_d2, G);
@@ -1048,6 +1088,33 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
 #endif
     if (agent_ok && r == 0)
         okStoreAgent(p.st, a, ag);
+    if (kPacked)
+    {
+        if (ray_ok)
+        {
+            p.hits_xy_out[2 * k]     = last_rel_x;
+            p.hits_xy_out[2 * k + 1] = last_rel_y;
+        }
+        if (agent_ok && r == 0)
+        {
+            okenv_agent_record rc;
+            rc.pos_x          = ag.pos_x;
+            rc.pos_y          = ag.pos_y;
+            rc.rot            = ag.rot;
+            rc.speed          = ag.speed;
+            rc.acc            = ag.acc;
+            rc.throttle       = ag.thr;
+            rc.steer          = ag.steer;
+            rc.disp_x         = ag.disp_x;
+            rc.disp_y         = ag.disp_y;
+            rc.disp_ctr       = ag.disp_ctr;
+            rc.mode           = static_cast<uint8_t>(ag.mode);
+            rc.crashed        = ag.crashed ? 1 : 0;
+            rc.timed_out      = ag.timed_out ? 1 : 0;
+            rc.disp_timed_out = ag.disp_to ? 1 : 0;
+            p.rec_out[a]      = rc;
+        }
+    }
     okAdvanceStepCounter(p);
 }
 
