@@ -5,6 +5,7 @@
 // draws nothing; it only invokes the user callback so that callers that count frames or log inside it keep working.
 #pragma once
 
+#include <cstdint>
 #include <functional>
 #include <vector>
 
@@ -24,6 +25,11 @@ OKENV_CLASS int GetRandomValue(int min, int max);
 
 namespace env
 {
+// The frame Visualizer::render draws in the reference (Visualizer.cpp:159-229), rasterised on the CPU into an RGBA8 buffer
+// (openkitchen_amd/csrc/facade/Visualizer.cpp).  `rays` may be null (draw_rays_ off).
+OKENV_CLASS void paintFrame(std::vector<uint8_t> &rgba, int width, int height, const RaceTrack &track, const std::vector<Agent *> &agents,
+                            const CollisionChecker *rays);
+
 class Visualizer
 {
   public:

@@ -19,6 +19,7 @@ CXX_SOURCES = [
     os.path.join(CSRC, "facade", "RaceTrack.cpp"),
     os.path.join(CSRC, "facade", "Agent.cpp"),
     os.path.join(CSRC, "facade", "Environment.cpp"),
+    os.path.join(CSRC, "facade", "Visualizer.cpp"),
 ]
 HEADERS = [
     os.path.join(CSRC, "ok_raycast.h"), os.path.join(CSRC, "ok_grid.h"), os.path.join(CSRC, "okenv_kernels.h"),

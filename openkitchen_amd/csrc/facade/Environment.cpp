@@ -286,6 +286,10 @@ Environment::Environment(const std::string &race_track_path, const std::vector<A
     track_segments_ = std::make_unique<TrackSegments>(*race_track_);
     visualizer_     = std::make_unique<env::Visualizer>(hidden_window);
     screen_grabber_ = std::make_unique<ScreenGrabber>(kScreenWidth, kScreenHeight);
+    // the frame is painted when somebody grabs it (Visualizer.cpp), from the state as it is then
+    screen_grabber_->setPainter([this](std::vector<uint8_t> &rgba, const int w, const int h) {
+        env::paintFrame(rgba, w, h, *race_track_, agents_, (draw_rays_ && collision_checker_) ? collision_checker_.get() : nullptr);
+    });
     agents_         = agents;
     displacement_stats_.resize(agents.size());
     if (!agents_.empty())
