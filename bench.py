@@ -141,8 +141,27 @@ def bench_callers(args, torch, local_rank, log):
         "workload": "population %d (reference: 20), 250 parameters, controller 5-16-8-2 in PyTorch, iteration replayed as one HIP "
                     "graph, index-progress fitness on the device; includes sampling and the host eigendecomposition" % N}
     racers.venv.close()
+    # the C++ drop-in classes (include/Environment/): microseconds per Environment::step() at the population sizes the
+    # reference's applications use (Template 1, PPO / REINFORCE 15, EvolutionaryRacer 50 agents); five-ray fan
+    try:
+        import subprocess
+        exe = os.path.join(ROOT, "tools", "_build", "facade_bench")
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "tools", "facade_bench.cpp"),
+                        "-L", os.path.join(ROOT, "openkitchen_amd"), "-lokenv", "-Wl,-rpath," + os.path.join(ROOT, "openkitchen_amd")], check=True)
+        r = subprocess.run([exe, ok_track_path(args.track), "2000", "1", "15", "50"], check=True, capture_output=True, text=True, timeout=120)
+        out["facade_step_us"] = {"agents_%s" % line.split()[0]: float(line.split()[1]) for line in r.stdout.strip().splitlines()}
+        out["facade_step_us"]["workload"] = ("Environment::step() of the C++ drop-in classes, five-ray agents on %s, resetAgent on crash, "
+                                            "one kernel per step over a host-mapped record buffer (okenv_step_packed)" % args.track)
+    except Exception as e:  # noqa: BLE001
+        out["facade_step_us"] = {"error": "%s: %s" % (type(e).__name__, e)}
     log("callers: %s" % out)
     return out
+
+
+def ok_track_path(name):
+    import openkitchen_amd as ok
+    return ok.track_path(name)
 
 
 def bench_evolution(args, ok, torch, dist, rank, world, local_rank, log):

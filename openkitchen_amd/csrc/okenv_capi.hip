@@ -86,6 +86,8 @@ struct okenv
     std::string last_error;
     bool        timing{false};
     std::vector<EventPair> events;      // recorded pairs awaiting resolution
+    double      timing_carry_ms{0.0};    // pairs resolved early (before a stream switch), not yet reported
+    uint64_t    timing_carry_n{0};
     std::vector<EventPair> event_pool;  // reusable pairs
 };
 
@@ -556,7 +558,11 @@ extern "C"
         if (!h)
             return OKENV_OK;
         (void)hipSetDevice(h->device);
-        (void)hipStreamSynchronize(h->stream);
+        // a borrowed stream (okenv_set_stream) may already be gone, or be capturing: wait for the device instead of touching it
+        if (h->own_stream)
+            (void)hipStreamSynchronize(h->stream);
+        else
+            (void)hipDeviceSynchronize();
         for (void *p : h->allocations)
             (void)hipFree(p);
         if (h->h_stage)
@@ -638,7 +644,22 @@ extern "C"
         // no synchronisation here: the call must be legal while the new stream is being captured into a graph; work
         // already queued on the old stream completes on its own (hipStreamDestroy defers), ordering is the caller's
         if (h->own_stream && h->stream)
+        {
+            // timing events recorded on the stream about to be destroyed are resolved first (nothing can be captured on a
+            // stream this handle owns, so waiting for them is legal here) and carried into the next okenv_get_timing
+            for (auto &e : h->events)
+            {
+                float ms = 0.F;
+                if (hipEventSynchronize(e.stop) == hipSuccess && hipEventElapsedTime(&ms, e.start, e.stop) == hipSuccess)
+                {
+                    h->timing_carry_ms += ms;
+                    ++h->timing_carry_n;
+                }
+                h->event_pool.push_back(e);
+            }
+            h->events.clear();
             (void)hipStreamDestroy(h->stream);
+        }
         h->stream     = static_cast<hipStream_t>(hip_stream);
         h->own_stream = false;
         return OKENV_OK;
@@ -1509,8 +1530,10 @@ extern "C"
             OK_HIP(h, hipEventElapsedTime(&ms, e.start, e.stop));
             sum += ms;
         }
-        *total_ms = sum;
-        *launches = h->events.size();
+        *total_ms = sum + h->timing_carry_ms;
+        *launches = h->events.size() + h->timing_carry_n;
+        h->timing_carry_ms = 0.0;
+        h->timing_carry_n  = 0;
         for (auto &e : h->events)
             h->event_pool.push_back(e);
         h->events.clear();

@@ -782,6 +782,10 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
                 leader = atomicMax(&lds_progress[my_simd], static_cast<uint32_t>(s));
             leader          = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(leader)));
             const int behind = static_cast<int>(leader) - s;
+#if defined(OKENV_PRIO_SLEEP) // experiment: a wave far ahead of the slowest of its SIMD also yields a little
+            if (behind < 0)
+                __builtin_amdgcn_s_sleep(OKENV_PRIO_SLEEP);
+#endif
             if (behind >= 3 * OKENV_PRIO_STEP)
                 __builtin_amdgcn_s_setprio(3);
             else if (behind >= 2 * OKENV_PRIO_STEP)
