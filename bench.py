@@ -432,6 +432,7 @@ def main():
             "ms_per_step_min": min(region_s) / args.steps * 1e3,
             "ms_per_step_max": max(region_s) / args.steps * 1e3,
             "spread": (max(region_s) - min(region_s)) / elapsed_max if elapsed_max > 0 else None,
+            "spread_p10_p90": float(np.percentile(region_s, 90) - np.percentile(region_s, 10)) / elapsed_max if elapsed_max > 0 else None,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
