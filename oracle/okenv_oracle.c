@@ -659,11 +659,39 @@ static void auto_reset_pass(oracle_env *e)
     }
 }
 
+/* Environment::step for every agent.  Agents are independent inside a step, so the tests may spread them over host
+ * threads (oracle_set_threads; default 1 -- the CPU baseline of bench.py times the single-threaded path). */
+#include <pthread.h>
+static int g_step_threads = 1;
+ORACLE_API void oracle_set_threads(int n) { g_step_threads = n < 1 ? 1 : n; }
+typedef struct { oracle_env *e; int a0, a1; } step_job;
+static void *step_job_main(void *p)
+{
+    step_job *j = (step_job *)p;
+    step_range(j->e, j->a0, j->a1);
+    return NULL;
+}
+static void step_all(oracle_env *e)
+{
+    int threads = g_step_threads > e->N ? e->N : g_step_threads;
+    if (threads <= 1 || e->N * e->R < 512) { step_range(e, 0, e->N); return; }
+    pthread_t th[64];
+    step_job jobs[64];
+    if (threads > 64) threads = 64;
+    for (int t = 0; t < threads; ++t) {
+        jobs[t].e = e;
+        jobs[t].a0 = (int)((long long)e->N * t / threads);
+        jobs[t].a1 = (int)((long long)e->N * (t + 1) / threads);
+        pthread_create(&th[t], NULL, step_job_main, &jobs[t]);
+    }
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+}
+
 ORACLE_API void oracle_env_step(oracle_env *e, int n_steps)
 {
     for (int s = 0; s < n_steps; ++s) {
         auto_reset_pass(e);
-        step_range(e, 0, e->N);
+        step_all(e);
         e->step_count++;
     }
 }
@@ -898,7 +926,7 @@ ORACLE_API void oracle_env_rollout_policy(oracle_env *e, int n_steps)
     for (int s = 0; s < n_steps; ++s) {
         for (int a = 0; a < e->N; ++a) ga_update_action(e, a);
         auto_reset_pass(e); /* off in the reference's loop; when on, a reset agent's step runs with the zeroed action */
-        step_range(e, 0, e->N);
+        step_all(e);
         e->step_count++;
     }
 }
@@ -1029,7 +1057,7 @@ ORACLE_API void oracle_q_begin_episode(oracle_env *e, int reset_idx)
     const float x = e->cx[reset_idx], y = e->cy[reset_idx];
     const int near = nearest_index(e, x, y);
     for (int a = 0; a < e->N; ++a) { agent_reset(e, a, x, y, e->chead[reset_idx]); e->q_prev[a] = near; }
-    step_range(e, 0, e->N);
+    step_all(e);
     for (int a = 0; a < e->N; ++a) e->q_state[a] = q_discretize(e, a);
 }
 
@@ -1054,7 +1082,7 @@ ORACLE_API void oracle_rollout_q(oracle_env *e, int n_steps, float epsilon, uint
             e->thr[a] = (act == 0) ? 60.0f : 30.0f;
             e->steer[a] = (act == 0) ? 0.0f : (act == 1 ? 5.0f : -5.0f);
         }
-        step_range(e, 0, e->N);
+        step_all(e);
         for (int a = 0; a < e->N; ++a) {
             const int next_state = q_discretize(e, a);
             float reward;

@@ -82,6 +82,7 @@ def lib():
         L.oracle_env_reset_agents.argtypes = [C.c_void_p, i32p, f32p, f32p, f32p, C.c_int]
         L.oracle_env_collide.argtypes = [C.c_void_p]
         L.oracle_env_step.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_set_threads.argtypes = [C.c_int]
         L.oracle_env_move_only.argtypes = [C.c_void_p]
         L.oracle_env_rollout_random.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]
         L.oracle_env_rollout_random_mt.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]

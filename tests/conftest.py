@@ -26,6 +26,9 @@ def _gpu_available():
 def oracle():
     import _oracle
     _oracle.build_oracle(with_ref=True)
+    # agents are independent inside a step: the oracle's Environment::step may use the host's cores (same bits, the GPU
+    # suite spends most of its time in the oracle's brute-force sweep)
+    _oracle.lib().oracle_set_threads(min(8, os.cpu_count() or 1))
     return _oracle
 
 

@@ -15,7 +15,7 @@ def test_ragged_shapes(gpu, oracle, N, R):
     orc.init_bench_state(0, 0)
     steps = 40 if N > 1000 else 150
     dev.rollout_random(steps, 11, 0, 0)
-    orc.rollout_random(steps, 11, 0, 0, threads=8 if N > 1000 else 1)
+    orc.rollout_random(steps, 11, 0, 0, threads=8 if N > 64 else 1)
     assert_same_state(dev.snapshot(), orc.snapshot(), "N=%d R=%d" % (N, R))
 
 

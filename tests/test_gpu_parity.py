@@ -93,7 +93,7 @@ def test_rollout_random_bit_exact(gpu, oracle, track_name, N, R, mode):
     crashes = 0
     for chunk in range(6):
         dev.rollout_random(75, 1234, 0, chunk * 75)
-        orc.rollout_random(75, 1234, 0, chunk * 75)
+        orc.rollout_random(75, 1234, 0, chunk * 75, threads=8)
         d, o = dev.snapshot(), orc.snapshot()
         assert_same_state(d, o, "chunk %d" % chunk)
         crashes += int(o["crashed"].sum())
@@ -176,7 +176,7 @@ def test_grid_forms_agree(gpu, oracle, flags):
     dev.init_bench_state(0, 0)
     orc.init_bench_state(0, 0)
     dev.rollout_random(120, 99, 0, 0)
-    orc.rollout_random(120, 99, 0, 0)
+    orc.rollout_random(120, 99, 0, 0, threads=8)
     assert_same_state(dev.snapshot(), orc.snapshot(), "flags %d" % flags)
 
 
@@ -187,7 +187,7 @@ def test_cell_size_does_not_change_results(gpu, oracle, cell):
     dev.init_bench_state(0, 0)
     orc.init_bench_state(0, 0)
     dev.rollout_random(150, 5, 0, 0)
-    orc.rollout_random(150, 5, 0, 0)
+    orc.rollout_random(150, 5, 0, 0, threads=8)
     assert_same_state(dev.snapshot(), orc.snapshot(), "cell %g" % cell)
 
 
