@@ -782,10 +782,6 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
                 leader = atomicMax(&lds_progress[my_simd], static_cast<uint32_t>(s));
             leader          = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(leader)));
             const int behind = static_cast<int>(leader) - s;
-#if defined(OKENV_PRIO_SLEEP) // experiment: a wave far ahead of the slowest of its SIMD also yields a little
-            if (behind < 0)
-                __builtin_amdgcn_s_sleep(OKENV_PRIO_SLEEP);
-#endif
             if (behind >= 3 * OKENV_PRIO_STEP)
                 __builtin_amdgcn_s_setprio(3);
             else if (behind >= 2 * OKENV_PRIO_STEP)
@@ -895,7 +891,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
             // min over the m lanes of a ray (consecutive lanes), then back to the owner
             const int first = unfinished ? rank * m : 0;
             float     mine  = OK_SENSOR_RANGE;
-#if !defined(OKENV_GATHER_COMBINE) // shuffle tree over the m lanes, then one pull by the owner (measured faster than the owner gathering all m)
+            // (the owner gathering all m results in one round trip measured slower than this shuffle tree plus one pull)
 #pragma unroll
             for (int off = 1; off < kMaxSplit; off <<= 1)
             {
@@ -904,14 +900,6 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
                     found = other;
             }
             mine = __shfl(found, first, 64);
-#else
-#pragma unroll
-            for (int i = 0; i < kMaxSplit; ++i)
-            {
-                const float other = __shfl(found, first + (i < m ? i : 0), 64);
-                mine              = (other < mine) ? other : mine;
-            }
-#endif
             if (unfinished && mine < min_t)
                 min_t = mine;
 #if OKENV_PRIO == 1
