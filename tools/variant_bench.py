@@ -24,10 +24,13 @@ N, R, track_name = %(N)d, %(R)d, %(track)r
 t = ok.Track(track_name)
 # parity: 192 agents, 60 steps of the bench recipe, every field bit for bit
 fan = ok.default_ray_fan(R)
-dev = ok.BatchedEnvironment(t.segments, 192, fan, device=0, centerline=(t.x, t.y, t.heading), grid_cell=cell)
-orc = O.OracleEnv(t.segments, 192, R, fan, (t.x, t.y, t.heading))
+PN = %(PN)d
+dev = ok.BatchedEnvironment(t.segments, PN, fan, device=0, centerline=(t.x, t.y, t.heading), grid_cell=cell)
+orc = O.OracleEnv(t.segments, PN, R, fan, (t.x, t.y, t.heading))
 dev.init_bench_state(0, 0); orc.init_bench_state(0, 0)
-dev.rollout_random(60, 1234, 0, 0); orc.rollout_random(60, 1234, 0, 0, threads=16)
+for c in range(6):
+    dev.rollout_random(10, 1234, 0, c * 10)
+orc.rollout_random(60, 1234, 0, 0, threads=32)
 d, o = dev.snapshot(), orc.snapshot()
 bad = [k for k in ("pos_x", "pos_y", "rot", "crashed", "timed_out", "hit_x", "hit_y", "rel_x", "rel_y", "dist")
        if not np.array_equal(np.ascontiguousarray(d[k]).view(np.uint8), np.ascontiguousarray(o[k]).view(np.uint8))]
@@ -54,7 +57,7 @@ def main():
     for spec in sys.argv[1:]:
         name, _, opts = spec.partition(":")
         env = dict(os.environ)
-        cell, N, R, track = 0.0, 4096, 64, "Silverstone"
+        cell, N, R, track, PN = 0.0, 4096, 64, "Silverstone", 192
         for kv in filter(None, opts.split(",")):
             k, v = kv.split("=")
             if k == "cell":
@@ -65,13 +68,15 @@ def main():
                 R = int(v)
             elif k == "track":
                 track = v
+            elif k == "PN":
+                PN = int(v)
             else:
                 env[k] = v
         lib = os.path.join(ROOT, "tools", "_build", "libokenv_%s.so" % name)
         if not O_built:
             subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
             O_built = True
-        code = CHILD % dict(root=ROOT, lib=lib, cell=cell, N=N, R=R, track=track, tag=spec)
+        code = CHILD % dict(root=ROOT, lib=lib, cell=cell, N=N, R=R, track=track, tag=spec, PN=PN)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         out = r.stdout.strip().splitlines()
         print(out[-1] if out else "%s: FAILED rc=%d %s" % (spec, r.returncode, r.stderr[-400:]), flush=True)
