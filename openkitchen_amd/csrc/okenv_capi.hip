@@ -6,9 +6,11 @@
 // okenv_create fails with OKENV_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -74,6 +76,10 @@ struct okenv
     // Q-learning state
     float   *d_q_table{nullptr};
     int32_t *d_q_state{nullptr}, *d_q_action{nullptr}, *d_q_prev{nullptr}, *d_q_reset_nearest{nullptr};
+    void    *d_scratch{nullptr};       // staging for calls that take host arrays (every user synchronises before it returns)
+    size_t   scratch_bytes{0};
+    float   *d_q_reset_query{nullptr}; // (x, y) of the episode's reset point, the query of its nearest-index kernel
+    float    q_reset_query[2]{0.F, 0.F}; // host copy the upload reads: lives as long as the handle
     float   *d_q_sums{nullptr};
     uint16_t *d_cl_start{nullptr}, *d_cl_idx{nullptr}; // centre line bucketed by grid cell (Q-learning's nearest index)
     size_t    cl_capacity{0};
@@ -82,6 +88,8 @@ struct okenv
     float    q_epsilon{0.F};
     std::vector<float> host_cx, host_cy, host_chead, host_ray_deg;
     bool        coop{false};        // cooperative two-phase kernel (LDS form, one ray per lane)
+    int         agents_per_block{0}; // coop, tiny populations: agents per workgroup (the other lanes only stage); 0 = dense
+    uint32_t    packed_seq{0};      // okenv_step_packed: sequence number of the last launch's completion word
     float       phase1_range{48.F}; // T1 of the cooperative kernel [px]
     std::string last_error;
     bool        timing{false};
@@ -124,6 +132,25 @@ int devAlloc(okenv *h, T **out, const size_t count)
     OK_HIP(h, hipMemsetAsync(p, 0, std::max<size_t>(count, 1) * sizeof(T), h->stream));
     h->allocations.push_back(p);
     *out = static_cast<T *>(p);
+    return OKENV_OK;
+}
+
+// Device staging space owned by the handle, grown on demand.  Each caller waits for the stream before it returns, so one
+// buffer serves them all; the stream-ordered pool (hipMallocAsync) is not used anywhere: a tiny upload into pool memory
+// that was freed again without a wait gave q_racer_sim's episodes two different outcomes from run to run.
+int deviceScratch(okenv *h, const size_t bytes, void **out)
+{
+    if (bytes > h->scratch_bytes)
+    {
+        OK_HIP(h, hipStreamSynchronize(h->stream)); // nobody is still reading the old one
+        uint8_t *p  = nullptr;
+        const int rc = devAlloc(h, &p, bytes + bytes / 2U);
+        if (rc != OKENV_OK)
+            return rc;
+        h->d_scratch     = p;
+        h->scratch_bytes = bytes + bytes / 2U;
+    }
+    *out = h->d_scratch;
     return OKENV_OK;
 }
 
@@ -206,6 +233,7 @@ OkStepParams baseParams(okenv *h)
     p.reset_seed    = h->reset_seed;
     p.agent_base    = h->reset_agent_base;
     p.step_counter  = h->d_step_count;
+    p.agents_per_block = h->coop ? h->agents_per_block : 0;
     p.lane_l        = h->d_lane_l;
     p.lane_r        = h->d_lane_r;
     p.mlp_w         = h->d_mlp_w;
@@ -313,6 +341,38 @@ int buildCenterlineBuckets(okenv *h)
     return OKENV_OK;
 }
 
+// okenv_step_packed: the step kernel's last workgroup stores the launch's sequence number into mapped host memory once all
+// results are there.  Spinning on that word returns about 5 us earlier than hipStreamSynchronize (which waits for the
+// queue's completion signal: 10.9 us against 6.0 us for an empty kernel on this machine).  The stream is asked now and
+// then, so that a failed launch ends in an error and not in an endless wait.
+constexpr size_t kDoneWordBytes = 128;
+
+int waitPackedDone(okenv *h, const volatile uint32_t *word, const uint32_t seq)
+{
+    for (;;)
+    {
+        for (int spin = 0; spin < 4096; ++spin)
+        {
+            if (*word == seq)
+            {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                return OKENV_OK;
+            }
+            __builtin_ia32_pause();
+        }
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q == hipErrorNotReady)
+            continue;
+        if (q != hipSuccess)
+            return fail(h, OKENV_ERR_HIP, std::string("okenv_step_packed: ") + hipGetErrorString(q));
+        // the stream has drained: the word is there by now, or the kernel never got to write it
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (*word == seq)
+            return OKENV_OK;
+        return fail(h, OKENV_ERR_HIP, "okenv_step_packed: the step kernel finished without announcing it");
+    }
+}
+
 int launchStep(okenv *h, const OkStepParams &p)
 {
     OK_HIP(h, hipSetDevice(h->device));
@@ -363,7 +423,7 @@ int launchStep(okenv *h, const OkStepParams &p)
 }
 
 // The step counter also lives on the device (it is the epoch of the auto-reset draws and must advance when a captured
-// graph of the step is replayed): okAdvanceStepCounter at the end of the step kernels.
+// graph of the step is replayed): okFinishLaunch at the end of the step kernels.
 int advanceStepCount(okenv *h, const int n_steps)
 {
     h->step_count += static_cast<uint32_t>(n_steps); // the device copy is advanced by the step kernel itself
@@ -489,7 +549,7 @@ extern "C"
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okDebugCastKernel<kGridLds>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->image_bytes)));
         }
-#if defined(OKENV_STAMPS)
+#if defined(OKENV_STAMPS) || defined(OKENV_PACKED_PROBE)
         if (h->grid_mode == kGridLds)
         { // diagnostic build: d_refs32 doubles as the stamp buffer (6 x u64 per wave)
             if ((rc = devAlloc(h, &h->d_refs32, static_cast<size_t>(num_agents) * 32U + 1024U)) != OKENV_OK)
@@ -542,6 +602,20 @@ extern "C"
         h->coop          = h->grid_mode == kGridLds && h->rays_per_lane == 1;
         if (const char *env_coop = std::getenv("OKENV_COOP")) // tuning/ablation knob: 0 = every lane walks its own ray to the end
             h->coop = h->coop && std::atoi(env_coop) != 0;
+        // up to 256 agents with a wave each (the populations of the reference's applications: 1, 15, 30, 50): one agent per
+        // workgroup, i.e. per CU -- four such waves on one CU take 7.8 us for a step, one alone 6.0 us -- and three more waves
+        // that only help with the staging
+        h->agents_per_block = 0;
+        if (h->coop && h->G == 64 && num_agents <= 256 && per_block == 256)
+            h->agents_per_block = 1;
+        if (const char *env_apb = std::getenv("OKENV_AGENTS_PER_BLOCK"))
+        { // tuning knob; 0 = dense
+            const int apb = std::atoi(env_apb);
+            if (h->coop && apb >= 0 && static_cast<long>(apb) * h->G <= per_block)
+                h->agents_per_block = apb;
+        }
+        if (h->agents_per_block > 0)
+            h->grid_blocks = (num_agents + h->agents_per_block - 1) / h->agents_per_block;
         if (const char *env_t1 = std::getenv("OKENV_PHASE1_RANGE"))
         {
             const float t1 = static_cast<float>(std::atof(env_t1));
@@ -761,7 +835,9 @@ extern "C"
         // one staging buffer: idx | x | y | rot
         const size_t bytes = static_cast<size_t>(n) * 16U;
         void        *stage = nullptr;
-        OK_HIP(h, hipMallocAsync(&stage, bytes, h->stream));
+        const int    src   = deviceScratch(h, bytes, &stage);
+        if (src != OKENV_OK)
+            return src;
         char *b = static_cast<char *>(stage);
         OK_HIP(h, hipMemcpyAsync(b, idx, 4U * n, hipMemcpyHostToDevice, h->stream));
         OK_HIP(h, hipMemcpyAsync(b + 4U * n, x, 4U * n, hipMemcpyHostToDevice, h->stream));
@@ -771,7 +847,6 @@ extern "C"
                            reinterpret_cast<const float *>(b + 4U * n), reinterpret_cast<const float *>(b + 8U * n),
                            reinterpret_cast<const float *>(b + 12U * n), n, h->N);
         OK_HIP(h, hipGetLastError());
-        OK_HIP(h, hipFreeAsync(stage, h->stream));
         OK_HIP(h, hipStreamSynchronize(h->stream));
         return OKENV_OK;
     }
@@ -823,17 +898,18 @@ extern "C"
         int32_t *didx = nullptr;
         if (idx)
         {
-            OK_HIP(h, hipMallocAsync(reinterpret_cast<void **>(&didx), 4U * static_cast<size_t>(n), h->stream));
+            void     *sp  = nullptr;
+            const int src = deviceScratch(h, 4U * static_cast<size_t>(n), &sp);
+            if (src != OKENV_OK)
+                return src;
+            didx = static_cast<int32_t *>(sp);
             OK_HIP(h, hipMemcpyAsync(didx, idx, 4U * static_cast<size_t>(n), hipMemcpyDefault, h->stream));
         }
         hipLaunchKernelGGL(okResetRandomKernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->st, didx, n, h->N, flags, seed, epoch,
                            agent_base, h->d_cx, h->d_cy, h->d_chead, h->d_lane_l, h->d_lane_r, h->P);
         OK_HIP(h, hipGetLastError());
         if (didx)
-        {
-            OK_HIP(h, hipFreeAsync(didx, h->stream));
-            OK_HIP(h, hipStreamSynchronize(h->stream)); // the caller may reuse idx
-        }
+            OK_HIP(h, hipStreamSynchronize(h->stream)); // the caller may reuse idx, the next call the staging space
         return OKENV_OK;
     }
 
@@ -959,7 +1035,9 @@ extern "C"
         if (!h->h_stage)
         { // both buffers are committed together: a failed second allocation must not leave a half-initialised pair behind
             void *pinned = nullptr, *mapped = nullptr;
-            OK_HIP(h, hipHostMalloc(&pinned, hit_off + hit_bytes, hipHostMallocMapped));
+            // coherent (fine-grained): the device's stores go straight to the host's memory, in order with the completion word
+            OK_HIP(h, hipHostMalloc(&pinned, hit_off + hit_bytes + kDoneWordBytes, hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(pinned, 0, hit_off + hit_bytes + kDoneWordBytes);
             uint8_t *d = nullptr;
             if (hipHostGetDevicePointer(&mapped, pinned, 0) != hipSuccess || devAlloc(h, &d, hit_off + hit_bytes) != OKENV_OK)
             {
@@ -980,17 +1058,58 @@ extern "C"
             p.rec_out        = reinterpret_cast<okenv_agent_record *>(hm + out_off);
             p.hits_xy_out    = reinterpret_cast<float *>(hm + hit_off);
             p.rec_with_stats = (flags & OKENV_PACKED_WITH_STATS) ? 1 : 0;
+            // the completion word sits behind the hits, on a cache line of its own
+            const size_t done_off = (hit_off + hit_bytes + 63U) & ~static_cast<size_t>(63U);
+            p.done_flag           = reinterpret_cast<uint32_t *>(hm + done_off);
+            p.done_seq            = ++h->packed_seq;
             if (flags & OKENV_PACKED_COLLIDE_ONLY)
             {
                 p.do_move     = 0;
                 p.reset_flags = 0;
             }
+#if defined(OKENV_PACKED_PROBE)
+            const auto pt0 = std::chrono::steady_clock::now();
+#endif
             const int rc = launchStep(h, p);
             if (rc != OKENV_OK)
                 return rc;
             if ((flags & OKENV_PACKED_COLLIDE_ONLY) == 0U)
                 advanceStepCount(h, 1);
-            OK_HIP(h, hipStreamSynchronize(h->stream));
+#if defined(OKENV_PACKED_PROBE)
+            const auto pt1 = std::chrono::steady_clock::now();
+#endif
+            {
+                const int wrc = waitPackedDone(h, reinterpret_cast<const volatile uint32_t *>(hs + done_off), p.done_seq);
+                if (wrc != OKENV_OK)
+                    return wrc;
+            }
+#if defined(OKENV_PACKED_PROBE)
+            {
+                const auto    pt2 = std::chrono::steady_clock::now();
+                static double acc_launch = 0, acc_sync = 0;
+                static long   calls = 0;
+                acc_launch += std::chrono::duration<double, std::micro>(pt1 - pt0).count();
+                acc_sync += std::chrono::duration<double, std::micro>(pt2 - pt1).count();
+                if (++calls % 1000 == 0)
+                {
+                    const int waves = static_cast<int>((static_cast<long>(h->N) * h->G + 63) / 64);
+                    std::vector<unsigned long long> st(16U * waves);
+                    (void)hipMemcpy(st.data(), h->d_refs32, 8U * st.size(), hipMemcpyDeviceToHost);
+                    unsigned long long t0 = ~0ULL, t5 = 0;
+                    double d[5] = {0, 0, 0, 0, 0};
+                    for (int w = 0; w < waves; ++w)
+                    {
+                        t0 = std::min(t0, st[16U * w]);
+                        t5 = std::max(t5, st[16U * w + 5]);
+                        for (int i = 0; i < 5; ++i)
+                            d[i] += static_cast<double>(st[16U * w + i + 1] - st[16U * w + i]) / waves / 100.0;
+                    }
+                    std::fprintf(stderr, "probe N=%d waves=%d block=%d: host launch %.2f us, sync wait %.2f us | kernel first-entry..last-exit %.2f us; per wave: stage %.2f, rec load %.2f, step %.2f, stores %.2f, counter %.2f us\n",
+                                 h->N, waves, h->block_threads, acc_launch / 1000, acc_sync / 1000, static_cast<double>(t5 - t0) / 100.0, d[0], d[1], d[2], d[3], d[4]);
+                    acc_launch = acc_sync = 0;
+                }
+            }
+#endif
             const okenv_agent_record *src = reinterpret_cast<const okenv_agent_record *>(hs + out_off);
             for (size_t i = 0; i < N; ++i)
             {
@@ -1102,17 +1221,15 @@ extern "C"
             n = h->N;
         if (n <= 0)
             return OKENV_OK;
-        float   *dq  = nullptr;
-        int32_t *dout = nullptr;
-        OK_HIP(h, hipMallocAsync(reinterpret_cast<void **>(&dout), 4U * n, h->stream));
+        void     *sp  = nullptr; // [ out: n x i32 | queries: 2n x f32 ]
+        const int src = deviceScratch(h, 12U * static_cast<size_t>(n), &sp);
+        if (src != OKENV_OK)
+            return src;
+        int32_t     *dout = static_cast<int32_t *>(sp);
+        float       *dq   = reinterpret_cast<float *>(dout + n);
         const float *dqx = h->st.pos_x, *dqy = h->st.pos_y;
         if (!agents)
         {
-            if (hipMallocAsync(reinterpret_cast<void **>(&dq), 8U * n, h->stream) != hipSuccess)
-            {
-                (void)hipFreeAsync(dout, h->stream);
-                return fail(h, OKENV_ERR_HIP, "okenv_nearest_track_idx: out of device memory");
-            }
             OK_HIP(h, hipMemcpyAsync(dq, qx, 4U * n, hipMemcpyDefault, h->stream));
             OK_HIP(h, hipMemcpyAsync(dq + n, qy, 4U * n, hipMemcpyDefault, h->stream));
             dqx = dq;
@@ -1122,9 +1239,6 @@ extern "C"
                            dout);
         OK_HIP(h, hipGetLastError());
         OK_HIP(h, hipMemcpyAsync(out, dout, 4U * n, hipMemcpyDefault, h->stream));
-        if (dq)
-            OK_HIP(h, hipFreeAsync(dq, h->stream));
-        OK_HIP(h, hipFreeAsync(dout, h->stream));
         OK_HIP(h, hipStreamSynchronize(h->stream));
         return OKENV_OK;
     }
@@ -1331,7 +1445,7 @@ extern "C"
         {
             if ((rc = devAlloc(h, &h->d_q_table, n)) || (rc = devAlloc(h, &h->d_q_state, static_cast<size_t>(h->N))) ||
                 (rc = devAlloc(h, &h->d_q_action, static_cast<size_t>(h->N))) || (rc = devAlloc(h, &h->d_q_prev, static_cast<size_t>(h->N))) ||
-                (rc = devAlloc(h, &h->d_q_reset_nearest, 4U)))
+                (rc = devAlloc(h, &h->d_q_reset_nearest, 4U)) || (rc = devAlloc(h, &h->d_q_reset_query, 4U)))
                 return rc;
         }
         hipLaunchKernelGGL(okQInitTableKernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, h->stream, h->d_q_table,
@@ -1368,13 +1482,14 @@ extern "C"
         if (rc != OKENV_OK)
             return rc;
         // prev_track_idx_ = findNearestTrackIndexBruteForce(reset point) (q_racer_sim.cpp:134-139); one query on the device
-        float *dq = nullptr;
-        OK_HIP(h, hipMallocAsync(reinterpret_cast<void **>(&dq), 8U, h->stream));
-        const float q[2] = {x, y};
-        OK_HIP(h, hipMemcpyAsync(dq, q, 8U, hipMemcpyHostToDevice, h->stream));
+        // (the query lives in the handle on both sides: an asynchronous copy out of a local variable may still be reading it
+        // after this function has returned)
+        h->q_reset_query[0] = x;
+        h->q_reset_query[1] = y;
+        float *dq           = h->d_q_reset_query;
+        OK_HIP(h, hipMemcpyAsync(dq, h->q_reset_query, 8U, hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(okNearestIdxKernel, dim3(1), dim3(256), 0, h->stream, h->d_cx, h->d_cy, h->P, dq, dq + 1, 1, h->d_q_reset_nearest);
         OK_HIP(h, hipGetLastError());
-        OK_HIP(h, hipFreeAsync(dq, h->stream));
         if ((rc = okenv_step(h, 1)) != OKENV_OK) // initial observation with the zero action Agent::reset leaves behind
             return rc;
         hipLaunchKernelGGL(okQBeginEpisodeKernel, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->st.dist, h->R, h->q_ray[0], h->q_ray[1],
@@ -1649,7 +1764,7 @@ extern "C"
         return OKENV_OK;
     }
 
-#if defined(OKENV_STAMPS)
+#if defined(OKENV_STAMPS) || defined(OKENV_PACKED_PROBE)
     __attribute__((visibility("default"))) int okenv_debug_stamps(okenv_t h, unsigned long long *out, int waves)
     {
         OK_HIP(h, hipStreamSynchronize(h->stream));
@@ -1688,8 +1803,11 @@ extern "C"
         if (n == 0)
             return OKENV_OK;
         OK_HIP(h, hipSetDevice(h->device));
-        float *d = nullptr;
-        OK_HIP(h, hipMallocAsync(reinterpret_cast<void **>(&d), 16U * static_cast<size_t>(n), h->stream));
+        void     *sp  = nullptr;
+        const int src = deviceScratch(h, 16U * static_cast<size_t>(n), &sp);
+        if (src != OKENV_OK)
+            return src;
+        float *d = static_cast<float *>(sp);
         OK_HIP(h, hipMemcpyAsync(d, ox, 4U * static_cast<size_t>(n), hipMemcpyHostToDevice, h->stream));
         OK_HIP(h, hipMemcpyAsync(d + n, oy, 4U * static_cast<size_t>(n), hipMemcpyHostToDevice, h->stream));
         OK_HIP(h, hipMemcpyAsync(d + 2 * static_cast<size_t>(n), angle_rad, 4U * static_cast<size_t>(n), hipMemcpyHostToDevice, h->stream));
@@ -1713,7 +1831,6 @@ extern "C"
         }
         OK_HIP(h, hipGetLastError());
         OK_HIP(h, hipMemcpyAsync(out_t, dt, 4U * static_cast<size_t>(n), hipMemcpyDeviceToHost, h->stream));
-        OK_HIP(h, hipFreeAsync(d, h->stream));
         OK_HIP(h, hipStreamSynchronize(h->stream));
         return OKENV_OK;
     }

@@ -105,6 +105,14 @@ struct OkStepParams
     okenv_agent_record       *rec_out;
     float                    *hits_xy_out;
     int                       rec_with_stats; // DisplacementStats travel in the records (else the device keeps its own)
+    // ... and the launch announces its end there as well: the last workgroup to finish stores `done_seq` to `done_flag`
+    // (mapped host memory) after every workgroup's results have left the device; the host spins on that word instead of
+    // waiting for the stream's completion signal (about 5 us less per facade step).  nullptr: no announcement.
+    uint32_t *done_flag;
+    uint32_t  done_seq;
+    // cooperative kernel, tiny populations: workgroup b holds agents [b * agents_per_block, (b + 1) * agents_per_block) in its
+    // first lanes and the rest of its lanes only help with staging the image.  0: agents are packed densely over the grid.
+    int agents_per_block;
 };
 
 constexpr uint32_t kAutoResetOn = 0x80000000U;
@@ -249,20 +257,30 @@ __device__ __forceinline__ void okStageImage(const OkStepParams &p, unsigned cha
     __syncthreads();
 }
 
-// End of a step launch: advance the device-side step counter once, by the last workgroup to get here.  Every workgroup
-// has read the counter for the last time before its own arrival, so the writer runs after all readers.
-__device__ __forceinline__ void okAdvanceStepCounter(const OkStepParams &p)
+// End of a step launch, by the last workgroup to get here (step_counter[1] counts the finished ones): advance the
+// device-side step counter once -- every workgroup has read it for the last time before its own arrival, so the writer runs
+// after all readers -- and, for the packed host exchange, tell the host that all results are in its memory.
+__device__ __forceinline__ void okFinishLaunch(const OkStepParams &p)
 {
-    if ((p.reset_flags & 0x80000000U) == 0U)
+    const bool advance = (p.reset_flags & 0x80000000U) != 0U;
+    if (!advance && p.done_flag == nullptr)
         return;
+    if (p.done_flag != nullptr)
+        __threadfence_system(); // each wave: its stores to the host have been acknowledged before it reports in
     __syncthreads();
     if (threadIdx.x == 0)
     {
         __threadfence();
         if (atomicAdd(&p.step_counter[1], 1U) == gridDim.x - 1U)
         {
-            p.step_counter[0] += static_cast<uint32_t>(p.n_steps);
+            if (advance)
+                p.step_counter[0] += static_cast<uint32_t>(p.n_steps);
             p.step_counter[1] = 0U;
+            if (p.done_flag != nullptr)
+            {
+                __threadfence_system();
+                __hip_atomic_store(p.done_flag, p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
@@ -621,7 +639,7 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
     }
     if (agent_ok && rlane == 0)
         okStoreAgent(p.st, a, ag);
-    okAdvanceStepCounter(p);
+    okFinishLaunch(p);
 }
 
 // Cooperative step kernel for the LDS form (one ray per lane).
@@ -665,6 +683,10 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
     extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
     // Q-learning scans the centre line every step (reward = progress along it): keep it in LDS, behind the image
     // LDS behind the image: four progress words (one per SIMD, see OKENV_PRIO below), then the Q-learning data
+#if defined(OKENV_PACKED_PROBE)
+    unsigned long long probe_t[6];
+    probe_t[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     uint32_t *lds_progress = reinterpret_cast<uint32_t *>(ok_lds + off_coop);
     float    *lds_cx     = reinterpret_cast<float *>(ok_lds + off_coop + 16);
     float    *lds_cy     = lds_cx + p.P;
@@ -687,25 +709,35 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
     }
     if (threadIdx.x < 4)
         lds_progress[threadIdx.x] = 0U;
+
+    const int G = p.G;
+    // lane -> (agent, ray): densely over the grid, or -- tiny populations -- a few agents in the first lanes of every workgroup
+    const long gl       = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int  in_block = static_cast<int>(threadIdx.x) / G;
+    const int  agent    = p.agents_per_block > 0 ? static_cast<int>(blockIdx.x) * p.agents_per_block + in_block : static_cast<int>(gl / G);
+    const int  r        = static_cast<int>(gl % G); // blockDim.x is a multiple of G
+    const bool agent_ok = agent < p.N && (p.agents_per_block <= 0 || in_block < p.agents_per_block);
+    const int  a        = agent_ok ? agent : 0;
+    const bool ray_ok   = agent_ok && (r < p.R);
+    const long k        = static_cast<long>(a) * p.R + (ray_ok ? r : 0);
+    // the agent's state is asked for before the image is staged, so that its round trip (to the host's memory over PCIe in the
+    // packed exchange: 1.5 us) runs under the staging instead of after it
+    const float ray_deg = p.ray_deg[ray_ok ? r : 0];
+    OkAgentRegs        ag = okLoadAgent(p.st, a);
+    okenv_agent_record rc_in{};
+    if (kPacked)
+        rc_in = p.rec_in[a];
     const OkPolyView view = okSetupView<kGridLds>(p, ok_lds); // ends with a barrier
+#if defined(OKENV_PACKED_PROBE)
+    probe_t[1] = __builtin_amdgcn_s_memrealtime();
+#endif
 #if OKENV_PRIO == 2
     // which of the CU's four SIMDs this wave runs on (HW_REG_HW_ID bits 5:4): waves of one SIMD compete for its issue slots
     const uint32_t my_simd = (__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4)) & 3U;
 #endif
-
-    const int  G        = p.G;
-    const long gl       = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const int  agent    = static_cast<int>(gl / G);
-    const int  r        = static_cast<int>(gl % G);
-    const bool agent_ok = agent < p.N;
-    const int  a        = agent_ok ? agent : 0;
-    const bool ray_ok   = agent_ok && (r < p.R);
-    const long k        = static_cast<long>(a) * p.R + (ray_ok ? r : 0);
-    const float ray_deg = p.ray_deg[ray_ok ? r : 0];
-    OkAgentRegs ag      = okLoadAgent(p.st, a);
     if (kPacked)
     { // the caller's Agent objects, as records in mapped host memory
-        const okenv_agent_record rc = p.rec_in[a];
+        const okenv_agent_record &rc = rc_in;
         ag.pos_x                    = rc.pos_x;
         ag.pos_y                    = rc.pos_y;
         ag.rot                      = rc.rot;
@@ -724,6 +756,10 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
             ag.disp_to  = rc.disp_timed_out != 0;
         }
     }
+#if defined(OKENV_PACKED_PROBE)
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(ag.pos_x), "v"(ag.disp_x) : "memory");
+    probe_t[2] = __builtin_amdgcn_s_memrealtime();
+#endif
     float       last_rel_x = 0.F, last_rel_y = 0.F; // kPacked: sensor_hits_ of the last step
     float       last_dist = (kPolicy != kPolicyNone && ray_ok) ? p.st.dist[k] : 0.F;
     int         q_state = 0, q_action = 0, q_prev = 0;
@@ -1078,6 +1114,10 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
                 dbg[w * 16 + 6 + i] = wprof[i];
     }
 #endif
+#if defined(OKENV_PACKED_PROBE)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(ag.pos_x), "v"(last_rel_x) : "memory");
+    probe_t[3] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (agent_ok && r == 0)
         okStoreAgent(p.st, a, ag);
     if (kPacked)
@@ -1107,7 +1147,20 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
             p.rec_out[a]      = rc;
         }
     }
-    okAdvanceStepCounter(p);
+#if defined(OKENV_PACKED_PROBE)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    probe_t[4] = __builtin_amdgcn_s_memrealtime();
+#endif
+    okFinishLaunch(p);
+#if defined(OKENV_PACKED_PROBE)
+    probe_t[5] = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0)
+    {
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(const_cast<uint32_t *>(p.g_refs32));
+        for (int i = 0; i < 6; ++i)
+            dbg[(gl >> 6) * 16 + i] = probe_t[i];
+    }
+#endif
 }
 
 // ---- small service kernels ------------------------------------------------------------------------------
