@@ -110,6 +110,10 @@ typedef struct okenv_info {
     int32_t grid_blocks;      /* workgroups per launch */
     int32_t lanes_per_agent;  /* G: power of two >= R, capped at 64 */
     int32_t device;
+    int32_t agents_per_block; /* > 0: tiny population, that many agents per workgroup (the other lanes only stage)   */
+    int32_t packed_resident;  /* 1: a resident step kernel is serving okenv_step_packed right now                    */
+    int32_t packed_resident_steps; /* okenv_step_packed calls served by a resident kernel so far                     */
+    int32_t packed_fallbacks; /* ... of which the resident kernel had left: redone by a launch of their own          */
 } okenv_info;
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */

@@ -52,7 +52,9 @@ class OkenvInfo(C.Structure):
     _fields_ = [("num_agents", C.c_int32), ("num_rays", C.c_int32), ("num_segments", C.c_int32),
                 ("grid_nx", C.c_int32), ("grid_ny", C.c_int32), ("grid_cell", C.c_float), ("grid_refs", C.c_int32),
                 ("grid_in_lds", C.c_int32), ("lds_bytes", C.c_int32), ("block_threads", C.c_int32),
-                ("grid_blocks", C.c_int32), ("lanes_per_agent", C.c_int32), ("device", C.c_int32)]
+                ("grid_blocks", C.c_int32), ("lanes_per_agent", C.c_int32), ("device", C.c_int32),
+                ("agents_per_block", C.c_int32), ("packed_resident", C.c_int32), ("packed_resident_steps", C.c_int32),
+                ("packed_fallbacks", C.c_int32)]
 
 
 class OkenvError(RuntimeError):

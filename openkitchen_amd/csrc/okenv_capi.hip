@@ -90,6 +90,16 @@ struct okenv
     bool        coop{false};        // cooperative two-phase kernel (LDS form, one ray per lane)
     int         agents_per_block{0}; // coop, tiny populations: agents per workgroup (the other lanes only stage); 0 = dense
     uint32_t    packed_seq{0};      // okenv_step_packed: sequence number of the last launch's completion word
+    // resident step kernel (okenv_step_packed called in quick succession, see startResident)
+    hipStream_t resident_stream{nullptr};
+    bool        resident{false};
+    int         resident_mode{-1};  // OKENV_RESIDENT: 0 never, 1 from the first eligible step on, default: after a run of quick steps
+    int         resident_steps{0}, resident_fallbacks{0}; // statistics (okenv_get_info)
+    int         resident_stall_us{0}; // OKENV_RESIDENT_STALL_US, fault injection for the tests: the host dawdles this long before
+                                      // it hands a step to the resident kernel, which has left by then
+    int         packed_streak{0};   // packed steps in a row that came within kResidentGapUs of the one before
+    std::chrono::steady_clock::time_point packed_last_end{};
+    size_t      stage_done_off{0}, stage_slots_off{0};
     float       phase1_range{48.F}; // T1 of the cooperative kernel [px]
     std::string last_error;
     bool        timing{false};
@@ -341,6 +351,76 @@ int buildCenterlineBuckets(okenv *h)
     return OKENV_OK;
 }
 
+// ---- resident step kernel ------------------------------------------------------------------------------------------------
+// The C++ facade's Environment::step() is one okenv_step_packed per step for 1-50 agents.  Launched one by one, such a
+// step costs ~19-22 us of which only ~6 us are the step: 3 us to enqueue the launch, ~3 us until its first wave runs, ~2-3 us
+// to stage the track image into LDS again, and the completion.  When the steps follow each other closely the kernel
+// therefore stays: every workgroup (one agent each) keeps the image in its LDS and watches its agent's 64-byte slot in
+// mapped host memory; the host puts the record there, the workgroup steps it and answers through the same record / hits /
+// completion word as a one-shot launch.  The kernel leaves by itself after kResidentIdleTicks without work -- so it can
+// never outlive its process by more than that -- or when the host says so; every other entry point of the C ABI stops it
+// first (OK_QUIESCE), so nothing else ever runs against the handle's state while it is resident.
+constexpr uint32_t kResidentIdleTicks = 30000U; // 100 MHz ticks: 300 us
+constexpr double   kResidentGapUs     = 100.0;  // the host treats the kernel as gone after this long without a step
+constexpr int      kResidentStreak    = 16;     // quick steps in a row before the kernel is made resident
+constexpr uint32_t kResidentExit      = 0xFFFFFFFFU;
+constexpr int      kResidentMaxAgents = 64;
+
+int stopResident(okenv *h)
+{
+    if (!h->resident)
+        return OKENV_OK;
+    volatile uint32_t *slots = reinterpret_cast<volatile uint32_t *>(static_cast<uint8_t *>(h->h_stage) + h->stage_slots_off);
+    for (int i = 0; i < h->N; ++i)
+        for (int q = 3; q < 16; q += 4)
+            slots[16 * i + q] = kResidentExit;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    h->resident      = false;
+    h->packed_streak = 0;
+    OK_HIP(h, hipStreamSynchronize(h->resident_stream));
+    // a step the kernel left half done (it timed out between two workgroups) may have left the finish counter behind
+    OK_HIP(h, hipMemsetAsync(h->d_step_count + 1, 0, sizeof(uint32_t), h->stream));
+    OK_HIP(h, hipStreamSynchronize(h->stream));
+    return OKENV_OK;
+}
+
+#define OK_QUIESCE(h)                                                                                                  \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if ((h) != nullptr && (h)->resident)                                                                           \
+        {                                                                                                              \
+            const int qrc_ = stopResident(h);                                                                          \
+            if (qrc_ != OKENV_OK)                                                                                      \
+                return qrc_;                                                                                           \
+        }                                                                                                              \
+    } while (0)
+
+// sequence numbers of packed steps: 0 is "nothing yet" and kResidentExit the resident kernel's order to leave
+uint32_t nextPackedSeq(okenv *h)
+{
+    h->packed_seq = okNextPackedSeq(h->packed_seq);
+    return h->packed_seq;
+}
+
+size_t coopLdsBytes(const okenv *h);
+
+// Starts the resident kernel on a stream of its own; `p` carries the exchange pointers of okenv_step_packed.
+int startResident(okenv *h, OkStepParams p, volatile uint32_t *slots)
+{
+    OK_HIP(h, hipStreamSynchronize(h->stream)); // whatever was enqueued against the state comes first
+    if (!h->resident_stream)
+        OK_HIP(h, hipStreamCreateWithFlags(&h->resident_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 16 * h->N; ++i)
+        slots[i] = 0U;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    p.done_seq = okNextPackedSeq(h->packed_seq); // the first number the kernel waits for
+    hipLaunchKernelGGL((okStepCoopKernel<kPolicyNone, true, true>), dim3(h->grid_blocks), dim3(h->block_threads), coopLdsBytes(h), h->resident_stream,
+                       p, static_cast<uint32_t>(h->image_bytes), h->phase1_range);
+    OK_HIP(h, hipGetLastError());
+    h->resident = true;
+    return OKENV_OK;
+}
+
 // okenv_step_packed: the step kernel's last workgroup stores the launch's sequence number into mapped host memory once all
 // results are there.  Spinning on that word returns about 5 us earlier than hipStreamSynchronize (which waits for the
 // queue's completion signal: 10.9 us against 6.0 us for an empty kernel on this machine).  The stream is asked now and
@@ -542,6 +622,8 @@ extern "C"
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, true>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, true, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyMlp>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyQ>),
@@ -549,7 +631,7 @@ extern "C"
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okDebugCastKernel<kGridLds>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->image_bytes)));
         }
-#if defined(OKENV_STAMPS) || defined(OKENV_PACKED_PROBE)
+#if defined(OKENV_STAMPS)
         if (h->grid_mode == kGridLds)
         { // diagnostic build: d_refs32 doubles as the stamp buffer (6 x u64 per wave)
             if ((rc = devAlloc(h, &h->d_refs32, static_cast<size_t>(num_agents) * 32U + 1024U)) != OKENV_OK)
@@ -616,6 +698,10 @@ extern "C"
         }
         if (h->agents_per_block > 0)
             h->grid_blocks = (num_agents + h->agents_per_block - 1) / h->agents_per_block;
+        if (const char *env_stall = std::getenv("OKENV_RESIDENT_STALL_US"))
+            h->resident_stall_us = std::atoi(env_stall);
+        if (const char *env_res = std::getenv("OKENV_RESIDENT")) // 0: never keep the packed-step kernel resident, 1: from the first step on
+            h->resident_mode = std::atoi(env_res);
         if (const char *env_t1 = std::getenv("OKENV_PHASE1_RANGE"))
         {
             const float t1 = static_cast<float>(std::atof(env_t1));
@@ -632,6 +718,10 @@ extern "C"
         if (!h)
             return OKENV_OK;
         (void)hipSetDevice(h->device);
+        if (h->resident)
+            (void)stopResident(h);
+        if (h->resident_stream)
+            (void)hipStreamDestroy(h->resident_stream);
         // a borrowed stream (okenv_set_stream) may already be gone, or be capturing: wait for the device instead of touching it
         if (h->own_stream)
             (void)hipStreamSynchronize(h->stream);
@@ -672,6 +762,10 @@ extern "C"
         out->lds_bytes       = h->grid_mode == kGridLds ? static_cast<int32_t>(h->image_bytes) : 0;
         out->block_threads   = h->block_threads;
         out->grid_blocks     = h->grid_blocks;
+        out->agents_per_block      = h->coop ? h->agents_per_block : 0;
+        out->packed_resident       = h->resident ? 1 : 0;
+        out->packed_resident_steps = h->resident_steps;
+        out->packed_fallbacks      = h->resident_fallbacks;
         out->lanes_per_agent = h->G;
         out->device          = h->device;
         return OKENV_OK;
@@ -681,12 +775,16 @@ extern "C"
     {
         if (!h)
             return OKENV_ERR_INVALID;
+        if (offset == h->sensor_offset)
+            return OKENV_OK; // the C++ facade says it before every step: not a reason to stop a resident step kernel
+        OK_QUIESCE(h);
         h->sensor_offset = offset;
         return OKENV_OK;
     }
 
     int okenv_set_centerline(okenv_t h, const float *x, const float *y, const float *heading_deg, int32_t num_points)
     {
+        OK_QUIESCE(h);
         if (!h || !x || !y || !heading_deg || num_points <= 0)
             return fail(h, OKENV_ERR_INVALID, "okenv_set_centerline: bad argument");
         OK_HIP(h, hipSetDevice(h->device));
@@ -713,6 +811,7 @@ extern "C"
 
     int okenv_set_stream(okenv_t h, void *hip_stream)
     {
+        OK_QUIESCE(h);
         if (!h)
             return OKENV_ERR_INVALID;
         // no synchronisation here: the call must be legal while the new stream is being captured into a graph; work
@@ -741,6 +840,7 @@ extern "C"
 
     int okenv_sync(okenv_t h)
     {
+        OK_QUIESCE(h);
         if (!h)
             return OKENV_ERR_INVALID;
         OK_HIP(h, hipStreamSynchronize(h->stream));
@@ -749,6 +849,7 @@ extern "C"
 
     int okenv_set_field(okenv_t h, int32_t field, const void *src)
     {
+        OK_QUIESCE(h);
         if (!h || !src)
             return fail(h, OKENV_ERR_INVALID, "okenv_set_field: NULL argument");
         const FieldDesc d = fieldOf(h, field);
@@ -763,6 +864,7 @@ extern "C"
 
     int okenv_get_field(okenv_t h, int32_t field, void *dst)
     {
+        OK_QUIESCE(h);
         if (!h || !dst)
             return fail(h, OKENV_ERR_INVALID, "okenv_get_field: NULL argument");
         const FieldDesc d = fieldOf(h, field);
@@ -806,16 +908,19 @@ extern "C"
 
     int okenv_upload_state(okenv_t h, const okenv_state_view *host_view)
     {
+        OK_QUIESCE(h);
         return moveState(h, host_view, true);
     }
 
     int okenv_download_state(okenv_t h, const okenv_state_view *host_view)
     {
+        OK_QUIESCE(h);
         return moveState(h, host_view, false);
     }
 
     int okenv_set_actions(okenv_t h, const float *throttle, const float *steer)
     {
+        OK_QUIESCE(h);
         if (!h || !throttle || !steer)
             return fail(h, OKENV_ERR_INVALID, "okenv_set_actions: NULL argument");
         int rc;
@@ -827,6 +932,7 @@ extern "C"
 
     int okenv_reset_agents(okenv_t h, const int32_t *idx, const float *x, const float *y, const float *rot_deg, int32_t n)
     {
+        OK_QUIESCE(h);
         if (!h || n < 0 || (n > 0 && (!idx || !x || !y || !rot_deg)))
             return fail(h, OKENV_ERR_INVALID, "okenv_reset_agents: bad argument");
         if (n == 0)
@@ -853,6 +959,7 @@ extern "C"
 
     int okenv_set_lane_bounds(okenv_t h, const float *left_inner_xy, const float *right_inner_xy, int32_t num_points)
     {
+        OK_QUIESCE(h);
         if (!h || !left_inner_xy || !right_inner_xy || num_points <= 0)
             return fail(h, OKENV_ERR_INVALID, "okenv_set_lane_bounds: bad argument");
         OK_HIP(h, hipSetDevice(h->device));
@@ -885,6 +992,7 @@ extern "C"
 
     int okenv_reset_random(okenv_t h, const int32_t *idx, int32_t n, uint32_t flags, uint32_t seed, uint32_t epoch, uint32_t agent_base)
     {
+        OK_QUIESCE(h);
         if (!h || n < 0)
             return fail(h, OKENV_ERR_INVALID, "okenv_reset_random: bad argument");
         if (!idx)
@@ -915,6 +1023,7 @@ extern "C"
 
     int okenv_set_auto_reset(okenv_t h, int32_t enabled, uint32_t flags, uint32_t seed, uint32_t agent_base)
     {
+        OK_QUIESCE(h);
         if (!h)
             return OKENV_ERR_INVALID;
         uint32_t count = 0;
@@ -938,6 +1047,7 @@ extern "C"
 
     int okenv_get_step_count(okenv_t h, uint32_t *out)
     {
+        OK_QUIESCE(h);
         if (!h || !out)
             return fail(h, OKENV_ERR_INVALID, "okenv_get_step_count: NULL argument");
         if ((h->reset_flags & kAutoResetOn) != 0U)
@@ -952,6 +1062,7 @@ extern "C"
 
     int okenv_set_step_count(okenv_t h, uint32_t value)
     {
+        OK_QUIESCE(h);
         if (!h)
             return OKENV_ERR_INVALID;
         h->step_count = value;
@@ -963,6 +1074,7 @@ extern "C"
 
     int okenv_field_device_ptr(okenv_t h, int32_t field, void **ptr, uint64_t *bytes)
     {
+        OK_QUIESCE(h);
         if (!h || !ptr)
             return fail(h, OKENV_ERR_INVALID, "okenv_field_device_ptr: NULL argument");
         const FieldDesc d = fieldOf(h, field);
@@ -976,6 +1088,7 @@ extern "C"
 
     int okenv_get_hits(okenv_t h, float *out_xy)
     {
+        OK_QUIESCE(h);
         if (!h || !out_xy)
             return fail(h, OKENV_ERR_INVALID, "okenv_get_hits: NULL argument");
         const size_t       NR = static_cast<size_t>(h->N) * h->R;
@@ -994,11 +1107,13 @@ extern "C"
 
     int okenv_get_distances(okenv_t h, float *out)
     {
+        OK_QUIESCE(h);
         return okenv_get_field(h, OKENV_F_DIST, out);
     }
 
     int okenv_get_flags(okenv_t h, uint8_t *out)
     {
+        OK_QUIESCE(h);
         if (!h || !out)
             return fail(h, OKENV_ERR_INVALID, "okenv_get_flags: NULL argument");
         std::vector<uint8_t> c(h->N), t(h->N);
@@ -1013,6 +1128,7 @@ extern "C"
 
     int okenv_step(okenv_t h, int32_t n_steps)
     {
+        OK_QUIESCE(h);
         if (!h || n_steps < 0)
             return fail(h, OKENV_ERR_INVALID, "okenv_step: bad argument");
         if (n_steps == 0)
@@ -1030,26 +1146,31 @@ extern "C"
         OK_HIP(h, hipSetDevice(h->device));
         const size_t N = static_cast<size_t>(h->N), NR = N * static_cast<size_t>(h->R);
         const size_t rec_bytes = N * sizeof(okenv_agent_record), hit_bytes = NR * 2U * sizeof(float);
-        const size_t out_off   = (rec_bytes + 255U) & ~static_cast<size_t>(255U); // [ in records | out records | hits ]
+        // mapped host memory: [ in records | out records | hits | completion word | one 64-byte slot per agent (resident kernel) ]
+        const size_t out_off   = (rec_bytes + 255U) & ~static_cast<size_t>(255U);
         const size_t hit_off   = 2U * out_off;
+        const size_t done_off  = (hit_off + hit_bytes + 63U) & ~static_cast<size_t>(63U);
+        const size_t slots_off = done_off + kDoneWordBytes;
+        const size_t stage_all = slots_off + 64U * N;
         if (!h->h_stage)
         { // both buffers are committed together: a failed second allocation must not leave a half-initialised pair behind
             void *pinned = nullptr, *mapped = nullptr;
             // coherent (fine-grained): the device's stores go straight to the host's memory, in order with the completion word
-            OK_HIP(h, hipHostMalloc(&pinned, hit_off + hit_bytes + kDoneWordBytes, hipHostMallocMapped | hipHostMallocCoherent));
-            std::memset(pinned, 0, hit_off + hit_bytes + kDoneWordBytes);
+            OK_HIP(h, hipHostMalloc(&pinned, stage_all, hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(pinned, 0, stage_all);
             uint8_t *d = nullptr;
             if (hipHostGetDevicePointer(&mapped, pinned, 0) != hipSuccess || devAlloc(h, &d, hit_off + hit_bytes) != OKENV_OK)
             {
                 (void)hipHostFree(pinned);
                 return fail(h, OKENV_ERR_HIP, "okenv_step_packed: cannot allocate the exchange buffers");
             }
-            h->h_stage        = pinned;
-            h->h_stage_device = mapped;
-            h->d_stage        = d;
+            h->h_stage         = pinned;
+            h->h_stage_device  = mapped;
+            h->d_stage         = d;
+            h->stage_done_off  = done_off;
+            h->stage_slots_off = slots_off;
         }
         uint8_t *hs = static_cast<uint8_t *>(h->h_stage), *ds = static_cast<uint8_t *>(h->d_stage);
-        std::memcpy(hs, in, rec_bytes);
         if (h->grid_mode == kGridLds && h->coop)
         { // ONE kernel: it reads the records from, and writes records and sensor_hits_ to, the mapped host buffer
             uint8_t     *hm = static_cast<uint8_t *>(h->h_stage_device);
@@ -1058,58 +1179,102 @@ extern "C"
             p.rec_out        = reinterpret_cast<okenv_agent_record *>(hm + out_off);
             p.hits_xy_out    = reinterpret_cast<float *>(hm + hit_off);
             p.rec_with_stats = (flags & OKENV_PACKED_WITH_STATS) ? 1 : 0;
-            // the completion word sits behind the hits, on a cache line of its own
-            const size_t done_off = (hit_off + hit_bytes + 63U) & ~static_cast<size_t>(63U);
-            p.done_flag           = reinterpret_cast<uint32_t *>(hm + done_off);
-            p.done_seq            = ++h->packed_seq;
-            if (flags & OKENV_PACKED_COLLIDE_ONLY)
-            {
-                p.do_move     = 0;
-                p.reset_flags = 0;
+            p.done_flag      = reinterpret_cast<uint32_t *>(hm + done_off); // behind the hits, on a cache line of its own
+            const volatile uint32_t *done_word = reinterpret_cast<const volatile uint32_t *>(hs + done_off);
+
+            // steps that follow each other closely are served by a resident kernel (see startResident)
+            const auto   t_in  = std::chrono::steady_clock::now();
+            const bool   quick = h->packed_seq != 0U && std::chrono::duration<double, std::micro>(t_in - h->packed_last_end).count() < kResidentGapUs;
+            h->packed_streak   = quick ? h->packed_streak + 1 : 0;
+            const bool eligible = h->resident_mode != 0 && h->agents_per_block == 1 && h->N <= kResidentMaxAgents && h->own_stream && !h->timing &&
+                                  (h->reset_flags & kAutoResetOn) == 0U && flags == OKENV_PACKED_WITH_STATS;
+            if (h->resident && (!eligible || !quick))
+            { // too long since the last step (the kernel may have left by itself), or a kind of step it does not serve
+                const int src = stopResident(h);
+                if (src != OKENV_OK)
+                    return src;
             }
-#if defined(OKENV_PACKED_PROBE)
-            const auto pt0 = std::chrono::steady_clock::now();
-#endif
-            const int rc = launchStep(h, p);
-            if (rc != OKENV_OK)
-                return rc;
-            if ((flags & OKENV_PACKED_COLLIDE_ONLY) == 0U)
-                advanceStepCount(h, 1);
-#if defined(OKENV_PACKED_PROBE)
-            const auto pt1 = std::chrono::steady_clock::now();
-#endif
+            const bool was_resident = h->resident;
+            if (!h->resident && eligible && (h->resident_mode == 1 || h->packed_streak >= kResidentStreak))
             {
-                const int wrc = waitPackedDone(h, reinterpret_cast<const volatile uint32_t *>(hs + done_off), p.done_seq);
+                p.slots          = reinterpret_cast<const uint32_t *>(hm + slots_off);
+                p.idle_ticks     = kResidentIdleTicks;
+                const int src = startResident(h, p, reinterpret_cast<volatile uint32_t *>(hs + slots_off));
+                if (src != OKENV_OK)
+                    return src;
+            }
+            bool served = false;
+            const bool just_started = !was_resident && h->resident;
+            if (h->resident)
+            {
+                if (h->resident_stall_us > 0 && h->resident_steps % 7 == 6)
+                { // (tests only) every seventh resident step comes too late
+                    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(h->resident_stall_us);
+                    while (std::chrono::steady_clock::now() < until)
+                    {
+                    }
+                }
+                const uint32_t     seq   = nextPackedSeq(h);
+                volatile uint32_t *slots = reinterpret_cast<volatile uint32_t *>(hs + slots_off);
+                for (size_t i = 0; i < N; ++i)
+                { // record word j goes to slot word j + j / 3: words 3, 7, 11, 15 of a slot carry the sequence number
+                    uint32_t w[sizeof(okenv_agent_record) / 4U];
+                    std::memcpy(w, &in[i], sizeof(okenv_agent_record));
+                    for (unsigned j = 0; j < sizeof(okenv_agent_record) / 4U; ++j)
+                        slots[16U * i + j + j / 3U] = w[j];
+                }
+                std::atomic_thread_fence(std::memory_order_release); // records before sequence numbers (and x86 keeps store order)
+                for (size_t i = 0; i < N; ++i)
+                    for (unsigned q = 3; q < 16U; q += 4U)
+                        slots[16U * i + q] = seq;
+                // wait for the answer; a kernel that has left (idle for too long, e.g. this thread was descheduled) never answers
+                bool       answered = false;
+                const auto t_asked  = std::chrono::steady_clock::now();
+                while (!answered)
+                {
+                    for (int spin = 0; spin < 1024 && !answered; ++spin)
+                    {
+                        answered = *done_word == seq;
+                        if (!answered)
+                            __builtin_ia32_pause();
+                    }
+                    // (a kernel launched a moment ago may still be on its way -- the first launch of a process loads the code
+                    // object -- and its patience only starts when it does)
+                    if (!answered && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_asked).count() >
+                                         (just_started ? 50000.0 : 2.5 * kResidentGapUs))
+                        break;
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+                ++h->resident_steps;
+                if (answered)
+                    served = true;
+                else
+                { // fall back to a launch of its own for this step: it works from the same input records
+                    ++h->resident_fallbacks;
+                    const int src = stopResident(h);
+                    if (src != OKENV_OK)
+                        return src;
+                }
+            }
+            if (!served)
+            {
+                std::memcpy(hs, in, rec_bytes);
+                p.slots    = nullptr;
+                p.done_seq = nextPackedSeq(h);
+                if (flags & OKENV_PACKED_COLLIDE_ONLY)
+                {
+                    p.do_move     = 0;
+                    p.reset_flags = 0;
+                }
+                const int rc = launchStep(h, p);
+                if (rc != OKENV_OK)
+                    return rc;
+                const int wrc = waitPackedDone(h, done_word, p.done_seq);
                 if (wrc != OKENV_OK)
                     return wrc;
             }
-#if defined(OKENV_PACKED_PROBE)
-            {
-                const auto    pt2 = std::chrono::steady_clock::now();
-                static double acc_launch = 0, acc_sync = 0;
-                static long   calls = 0;
-                acc_launch += std::chrono::duration<double, std::micro>(pt1 - pt0).count();
-                acc_sync += std::chrono::duration<double, std::micro>(pt2 - pt1).count();
-                if (++calls % 1000 == 0)
-                {
-                    const int waves = static_cast<int>((static_cast<long>(h->N) * h->G + 63) / 64);
-                    std::vector<unsigned long long> st(16U * waves);
-                    (void)hipMemcpy(st.data(), h->d_refs32, 8U * st.size(), hipMemcpyDeviceToHost);
-                    unsigned long long t0 = ~0ULL, t5 = 0;
-                    double d[5] = {0, 0, 0, 0, 0};
-                    for (int w = 0; w < waves; ++w)
-                    {
-                        t0 = std::min(t0, st[16U * w]);
-                        t5 = std::max(t5, st[16U * w + 5]);
-                        for (int i = 0; i < 5; ++i)
-                            d[i] += static_cast<double>(st[16U * w + i + 1] - st[16U * w + i]) / waves / 100.0;
-                    }
-                    std::fprintf(stderr, "probe N=%d waves=%d block=%d: host launch %.2f us, sync wait %.2f us | kernel first-entry..last-exit %.2f us; per wave: stage %.2f, rec load %.2f, step %.2f, stores %.2f, counter %.2f us\n",
-                                 h->N, waves, h->block_threads, acc_launch / 1000, acc_sync / 1000, static_cast<double>(t5 - t0) / 100.0, d[0], d[1], d[2], d[3], d[4]);
-                    acc_launch = acc_sync = 0;
-                }
-            }
-#endif
+            if ((flags & OKENV_PACKED_COLLIDE_ONLY) == 0U)
+                advanceStepCount(h, 1);
             const okenv_agent_record *src = reinterpret_cast<const okenv_agent_record *>(hs + out_off);
             for (size_t i = 0; i < N; ++i)
             {
@@ -1124,8 +1289,10 @@ extern "C"
                 out[i] = r;
             }
             std::memcpy(sensor_hits_xy, hs + hit_off, hit_bytes);
+            h->packed_last_end = std::chrono::steady_clock::now();
             return OKENV_OK;
         }
+        std::memcpy(hs, in, rec_bytes);
         OK_HIP(h, hipMemcpyAsync(ds, hs, rec_bytes, hipMemcpyHostToDevice, h->stream));
         const unsigned blocks_n = static_cast<unsigned>((N + 255U) / 256U);
         hipLaunchKernelGGL(okUnpackRecordsKernel, dim3(blocks_n), dim3(256), 0, h->stream, h->st,
@@ -1168,6 +1335,7 @@ extern "C"
 
     int okenv_collide(okenv_t h)
     {
+        OK_QUIESCE(h);
         if (!h)
             return OKENV_ERR_INVALID;
         OkStepParams p = baseParams(h);
@@ -1178,6 +1346,7 @@ extern "C"
 
     int okenv_rollout_random(okenv_t h, int32_t n_steps, uint32_t seed, uint32_t agent_base, uint32_t step_base)
     {
+        OK_QUIESCE(h);
         if (!h || n_steps < 0)
             return fail(h, OKENV_ERR_INVALID, "okenv_rollout_random: bad argument");
         if (h->P <= 0)
@@ -1196,6 +1365,7 @@ extern "C"
 
     int okenv_init_bench_state(okenv_t h, uint32_t agent_base, int32_t mode)
     {
+        OK_QUIESCE(h);
         if (!h)
             return OKENV_ERR_INVALID;
         if (h->P <= 0)
@@ -1209,6 +1379,7 @@ extern "C"
 
     int okenv_nearest_track_idx(okenv_t h, const float *qx, const float *qy, int32_t n, int32_t *out)
     {
+        OK_QUIESCE(h);
         if (!h || !out)
             return fail(h, OKENV_ERR_INVALID, "okenv_nearest_track_idx: NULL argument");
         if (h->P <= 0)
@@ -1247,6 +1418,7 @@ extern "C"
 
     int okenv_tracker_create(okenv_t h, int32_t reward_kind)
     {
+        OK_QUIESCE(h);
         if (!h || (reward_kind != OKENV_REWARD_STEP && reward_kind != OKENV_REWARD_PROGRESS))
             return fail(h, OKENV_ERR_INVALID, "okenv_tracker_create: unknown reward kind");
         if (h->P <= 0)
@@ -1281,11 +1453,13 @@ extern "C"
 
     int okenv_tracker_begin(okenv_t h)
     {
+        OK_QUIESCE(h);
         return launchTracker(h, 1, "okenv_tracker_begin");
     }
 
     int okenv_tracker_update(okenv_t h)
     {
+        OK_QUIESCE(h);
         return launchTracker(h, 0, "okenv_tracker_update");
     }
 
@@ -1293,6 +1467,7 @@ extern "C"
 
     int okenv_policy_mlp_create(okenv_t h, int32_t hidden, uint32_t seed, uint32_t agent_base)
     {
+        OK_QUIESCE(h);
         if (!h || hidden < 1 || hidden > OK_MLP_HID_PAD)
             return fail(h, OKENV_ERR_INVALID, "okenv_policy_mlp_create: hidden width must be in [1, 32]");
         if (h->rays_per_lane != 1 || h->R < 5 || h->G < 8)
@@ -1321,6 +1496,7 @@ extern "C"
 
     int okenv_policy_mlp_get_weights(okenv_t h, float *out)
     {
+        OK_QUIESCE(h);
         if (!h || !out || !h->d_mlp_w)
             return fail(h, OKENV_ERR_STATE, "okenv_policy_mlp_get_weights: no policy");
         int rc = copyAny(h, out, h->d_mlp_w, sizeof(float) * static_cast<size_t>(h->N) * OK_MLP_WEIGHTS(h->R));
@@ -1332,6 +1508,7 @@ extern "C"
 
     int okenv_policy_mlp_set_weights(okenv_t h, const float *in)
     {
+        OK_QUIESCE(h);
         if (!h || !in || !h->d_mlp_w)
             return fail(h, OKENV_ERR_STATE, "okenv_policy_mlp_set_weights: no policy");
         int rc = copyAny(h, h->d_mlp_w, in, sizeof(float) * static_cast<size_t>(h->N) * OK_MLP_WEIGHTS(h->R));
@@ -1343,6 +1520,7 @@ extern "C"
 
     int okenv_rollout_policy(okenv_t h, int32_t n_steps)
     {
+        OK_QUIESCE(h);
         if (!h || n_steps < 0)
             return fail(h, OKENV_ERR_INVALID, "okenv_rollout_policy: bad argument");
         if (!h->d_mlp_w)
@@ -1358,6 +1536,7 @@ extern "C"
 
     int okenv_alive_count(okenv_t h, int32_t *out)
     {
+        OK_QUIESCE(h);
         if (!h || !out)
             return fail(h, OKENV_ERR_INVALID, "okenv_alive_count: NULL argument");
         OK_HIP(h, hipSetDevice(h->device));
@@ -1379,6 +1558,7 @@ extern "C"
 
     int okenv_reset_all(okenv_t h, float x, float y, float rot_deg)
     {
+        OK_QUIESCE(h);
         if (!h)
             return OKENV_ERR_INVALID;
         OK_HIP(h, hipSetDevice(h->device));
@@ -1389,6 +1569,7 @@ extern "C"
 
     int okenv_ga_scores(okenv_t h, float *out)
     {
+        OK_QUIESCE(h);
         if (!h)
             return OKENV_ERR_INVALID;
         if (!h->d_mlp_w || h->P <= 0)
@@ -1410,6 +1591,7 @@ extern "C"
 
     int okenv_ga_select_mate(okenv_t h, uint32_t seed, uint32_t generation, uint32_t agent_base, int32_t *parents_out)
     {
+        OK_QUIESCE(h);
         if (!h)
             return OKENV_ERR_INVALID;
         if (!h->d_mlp_w)
@@ -1434,6 +1616,7 @@ extern "C"
 
     int okenv_q_create(okenv_t h)
     {
+        OK_QUIESCE(h);
         if (!h)
             return OKENV_ERR_INVALID;
         if (!h->coop || h->R < 5)
@@ -1473,6 +1656,7 @@ extern "C"
 
     int okenv_q_begin_episode(okenv_t h, int32_t reset_idx)
     {
+        OK_QUIESCE(h);
         if (!h || !h->d_q_table)
             return fail(h, OKENV_ERR_STATE, "okenv_q_begin_episode: call okenv_q_create first");
         if (h->P <= 0 || reset_idx < 0 || reset_idx >= h->P)
@@ -1500,6 +1684,7 @@ extern "C"
 
     int okenv_rollout_q(okenv_t h, int32_t n_steps, float epsilon, uint32_t seed, uint32_t agent_base, uint32_t step_base)
     {
+        OK_QUIESCE(h);
         if (!h || n_steps < 0)
             return fail(h, OKENV_ERR_INVALID, "okenv_rollout_q: bad argument");
         if (!h->d_q_table)
@@ -1525,6 +1710,7 @@ extern "C"
 
     int okenv_q_get_table(okenv_t h, float *out)
     {
+        OK_QUIESCE(h);
         if (!h || !out || !h->d_q_table)
             return fail(h, OKENV_ERR_STATE, "okenv_q_get_table: no table");
         int rc = copyAny(h, out, h->d_q_table, sizeof(float) * static_cast<size_t>(h->N) * OK_Q_STATES * OK_Q_ACTIONS);
@@ -1536,6 +1722,7 @@ extern "C"
 
     int okenv_q_set_table(okenv_t h, const float *in)
     {
+        OK_QUIESCE(h);
         if (!h || !in || !h->d_q_table)
             return fail(h, OKENV_ERR_STATE, "okenv_q_set_table: no table");
         int rc = copyAny(h, h->d_q_table, in, sizeof(float) * static_cast<size_t>(h->N) * OK_Q_STATES * OK_Q_ACTIONS);
@@ -1547,6 +1734,7 @@ extern "C"
 
     int okenv_q_get_state(okenv_t h, int32_t *state, int32_t *action, int32_t *prev_idx)
     {
+        OK_QUIESCE(h);
         if (!h || !h->d_q_table)
             return fail(h, OKENV_ERR_STATE, "okenv_q_get_state: no table");
         int rc;
@@ -1578,6 +1766,7 @@ extern "C"
 
     int okenv_q_table_sums(okenv_t h, float *sum, float *count)
     {
+        OK_QUIESCE(h);
         if (!sum || !count)
             return fail(h, OKENV_ERR_INVALID, "okenv_q_table_sums: NULL argument");
         float *d  = nullptr;
@@ -1593,6 +1782,7 @@ extern "C"
 
     int okenv_q_assign_mean(okenv_t h, const float *sum, const float *count)
     {
+        OK_QUIESCE(h);
         if (!h || !h->d_q_table || !sum || !count)
             return fail(h, OKENV_ERR_STATE, "okenv_q_assign_mean: no Q table or NULL argument");
         OK_HIP(h, hipSetDevice(h->device));
@@ -1618,6 +1808,7 @@ extern "C"
 
     int okenv_q_share_knowledge(okenv_t h)
     {
+        OK_QUIESCE(h);
         float *d  = nullptr;
         int    rc = qSums(h, &d);
         if (rc != OKENV_OK)
@@ -1627,6 +1818,7 @@ extern "C"
 
     int okenv_set_timing(okenv_t h, int32_t enabled)
     {
+        OK_QUIESCE(h);
         if (!h)
             return OKENV_ERR_INVALID;
         h->timing = enabled != 0;
@@ -1635,6 +1827,7 @@ extern "C"
 
     int okenv_get_timing(okenv_t h, double *total_ms, uint64_t *launches)
     {
+        OK_QUIESCE(h);
         if (!h || !total_ms || !launches)
             return fail(h, OKENV_ERR_INVALID, "okenv_get_timing: NULL argument");
         OK_HIP(h, hipStreamSynchronize(h->stream));
@@ -1764,9 +1957,10 @@ extern "C"
         return OKENV_OK;
     }
 
-#if defined(OKENV_STAMPS) || defined(OKENV_PACKED_PROBE)
+#if defined(OKENV_STAMPS)
     __attribute__((visibility("default"))) int okenv_debug_stamps(okenv_t h, unsigned long long *out, int waves)
     {
+        OK_QUIESCE(h);
         OK_HIP(h, hipStreamSynchronize(h->stream));
         OK_HIP(h, hipMemcpy(out, h->d_refs32, sizeof(unsigned long long) * 16U * waves, hipMemcpyDeviceToHost));
         return OKENV_OK;
@@ -1798,6 +1992,7 @@ extern "C"
 
     int okenv_debug_cast_rays(okenv_t h, const float *ox, const float *oy, const float *angle_rad, int32_t n, float *out_t)
     {
+        OK_QUIESCE(h);
         if (!h || !ox || !oy || !angle_rad || !out_t || n < 0)
             return fail(h, OKENV_ERR_INVALID, "okenv_debug_cast_rays: bad argument");
         if (n == 0)

@@ -113,7 +113,19 @@ struct OkStepParams
     // cooperative kernel, tiny populations: workgroup b holds agents [b * agents_per_block, (b + 1) * agents_per_block) in its
     // first lanes and the rest of its lanes only help with staging the image.  0: agents are packed densely over the grid.
     int agents_per_block;
+    // resident form of the packed exchange (okStepCoopKernel<.., true, true>): one 64-byte slot per agent in mapped host memory,
+    // words 3, 7, 11, 15 = sequence number, the other twelve = the agent's record (word j at j + j / 3); idle_ticks: how long
+    // (100 MHz ticks) a workgroup waits for work before it leaves
+    const uint32_t *slots;
+    uint32_t        idle_ticks;
 };
+
+// sequence numbers of packed steps (host and device count alike): 0 = nothing yet, 0xFFFFFFFF = "leave"
+__host__ __device__ inline uint32_t okNextPackedSeq(uint32_t s)
+{
+    ++s;
+    return (s == 0U || s == 0xFFFFFFFFU) ? 1U : s;
+}
 
 constexpr uint32_t kAutoResetOn = 0x80000000U;
 
@@ -677,16 +689,12 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
 #endif
 constexpr int kMaxSplit = OKENV_MAX_SPLIT; // intervals a pending ray is cut into at most
 
-template <int kPolicy, bool kPacked = false>
+template <int kPolicy, bool kPacked = false, bool kResident = false>
 __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, const uint32_t off_coop, const float phase1_range)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
     // Q-learning scans the centre line every step (reward = progress along it): keep it in LDS, behind the image
     // LDS behind the image: four progress words (one per SIMD, see OKENV_PRIO below), then the Q-learning data
-#if defined(OKENV_PACKED_PROBE)
-    unsigned long long probe_t[6];
-    probe_t[0] = __builtin_amdgcn_s_memrealtime();
-#endif
     uint32_t *lds_progress = reinterpret_cast<uint32_t *>(ok_lds + off_coop);
     float    *lds_cx     = reinterpret_cast<float *>(ok_lds + off_coop + 16);
     float    *lds_cy     = lds_cx + p.P;
@@ -723,18 +731,61 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
     // the agent's state is asked for before the image is staged, so that its round trip (to the host's memory over PCIe in the
     // packed exchange: 1.5 us) runs under the staging instead of after it
     const float ray_deg = p.ray_deg[ray_ok ? r : 0];
-    OkAgentRegs        ag = okLoadAgent(p.st, a);
+    OkAgentRegs        ag{};
     okenv_agent_record rc_in{};
-    if (kPacked)
-        rc_in = p.rec_in[a];
+    if (!kResident)
+    {
+        ag = okLoadAgent(p.st, a);
+        if (kPacked)
+            rc_in = p.rec_in[a];
+    }
     const OkPolyView view = okSetupView<kGridLds>(p, ok_lds); // ends with a barrier
-#if defined(OKENV_PACKED_PROBE)
-    probe_t[1] = __builtin_amdgcn_s_memrealtime();
-#endif
 #if OKENV_PRIO == 2
     // which of the CU's four SIMDs this wave runs on (HW_REG_HW_ID bits 5:4): waves of one SIMD compete for its issue slots
     const uint32_t my_simd = (__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4)) & 3U;
 #endif
+    // Resident form (host side: startResident in okenv_capi.hip): one agent per workgroup and per wave (G == 64); the waves that
+    // only helped with the staging leave, the agent's wave serves one step per pass of the loop below until it is told to go or
+    // has waited idle_ticks for nothing.
+    if (kResident && __ballot(agent_ok) == 0ULL)
+        return;
+    uint32_t res_seq = p.done_seq; // the sequence number this wave waits for
+    for (;;) // (left at the bottom unless kResident)
+    {
+    if (kResident)
+    {
+        // The slot is one 64-byte line of the host's memory, fetched by ONE load of 16 lanes.  Words 3, 7, 11, 15 hold the
+        // sequence number, written by the host after the record words: a 16-byte piece of the line that shows the new number
+        // was read after its record words were written, whatever the pieces a PCIe read may be served in.
+        const int                lane = static_cast<int>(threadIdx.x) & 63;
+        const uint32_t          *slot = p.slots + static_cast<size_t>(a) * 16U;
+        const unsigned long long t0   = __builtin_amdgcn_s_memrealtime();
+        uint32_t                 w    = 0U;
+        bool                     go   = false;
+        for (;;)
+        {
+            w = (lane < 16) ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0U;
+            const uint32_t s0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w), 3));
+            const uint32_t s1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w), 7));
+            const uint32_t s2 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w), 11));
+            const uint32_t s3 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w), 15));
+            if (s0 == s1 && s1 == s2 && s2 == s3 && (s0 == res_seq || s0 == 0xFFFFFFFFU))
+            {
+                go = s0 == res_seq;
+                break;
+            }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > static_cast<unsigned long long>(p.idle_ticks))
+                break; // nobody has asked for a step for a long time (or ever will: the process may be gone)
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!go)
+            break;
+        uint32_t rw[sizeof(okenv_agent_record) / 4U];
+#pragma unroll
+        for (unsigned j = 0; j < sizeof(okenv_agent_record) / 4U; ++j)
+            rw[j] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w), j + j / 3U));
+        __builtin_memcpy(&rc_in, rw, sizeof(okenv_agent_record));
+    }
     if (kPacked)
     { // the caller's Agent objects, as records in mapped host memory
         const okenv_agent_record &rc = rc_in;
@@ -756,10 +807,6 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
             ag.disp_to  = rc.disp_timed_out != 0;
         }
     }
-#if defined(OKENV_PACKED_PROBE)
-    asm volatile("s_waitcnt vmcnt(0)" ::"v"(ag.pos_x), "v"(ag.disp_x) : "memory");
-    probe_t[2] = __builtin_amdgcn_s_memrealtime();
-#endif
     float       last_rel_x = 0.F, last_rel_y = 0.F; // kPacked: sensor_hits_ of the last step
     float       last_dist = (kPolicy != kPolicyNone && ray_ok) ? p.st.dist[k] : 0.F;
     int         q_state = 0, q_action = 0, q_prev = 0;
@@ -1114,10 +1161,6 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
                 dbg[w * 16 + 6 + i] = wprof[i];
     }
 #endif
-#if defined(OKENV_PACKED_PROBE)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(ag.pos_x), "v"(last_rel_x) : "memory");
-    probe_t[3] = __builtin_amdgcn_s_memrealtime();
-#endif
     if (agent_ok && r == 0)
         okStoreAgent(p.st, a, ag);
     if (kPacked)
@@ -1147,20 +1190,26 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
             p.rec_out[a]      = rc;
         }
     }
-#if defined(OKENV_PACKED_PROBE)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    probe_t[4] = __builtin_amdgcn_s_memrealtime();
-#endif
-    okFinishLaunch(p);
-#if defined(OKENV_PACKED_PROBE)
-    probe_t[5] = __builtin_amdgcn_s_memrealtime();
-    if ((threadIdx.x & 63) == 0)
+    if (!kResident)
     {
-        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(const_cast<uint32_t *>(p.g_refs32));
-        for (int i = 0; i < 6; ++i)
-            dbg[(gl >> 6) * 16 + i] = probe_t[i];
+        okFinishLaunch(p);
+        break;
     }
-#endif
+    // resident: this wave is all that is left of its workgroup.  Its results have left the device before it reports in; the
+    // last workgroup to do so answers the host (which asks for the next step only after that, so one counter is enough).
+    __threadfence_system();
+    if ((threadIdx.x & 63U) == 0U)
+    {
+        __threadfence();
+        if (atomicAdd(&p.step_counter[1], 1U) == gridDim.x - 1U)
+        {
+            p.step_counter[1] = 0U;
+            __threadfence_system();
+            __hip_atomic_store(p.done_flag, res_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    res_seq = okNextPackedSeq(res_seq);
+    } // for (;;)
 }
 
 // ---- small service kernels ------------------------------------------------------------------------------

@@ -1,0 +1,129 @@
+"""The resident form of okenv_step_packed (the C++ facade's Environment::step in a tight loop): a kernel that stays on the
+GPU and takes one step per hand-over through mapped host memory.  Every step is compared with the oracle, through the start
+of the resident kernel, other C-ABI calls in between (which stop it), pauses longer than its idle time, and steps the host
+hands over too late (the kernel has left: the step is redone by a launch of its own)."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+from test_gpu_packed_step import ORACLE_KEYS, REC, WITH_STATS, packed_step
+
+pytestmark = pytest.mark.gpu
+
+
+def make(gpu, oracle, N, R, track="Austin", seed=0):
+    t = gpu.Track(track)
+    fan = np.array([-70, -30, 0, 30, 70], dtype=np.float32) if R == 5 else gpu.default_ray_fan(R)
+    dev = gpu.BatchedEnvironment.from_track(t, N, ray_angles_deg=fan)
+    orc = oracle.OracleEnv(t.segments, N, R, fan, (t.x, t.y, t.heading))
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(0, t.P, N)
+    rec = np.zeros(N, dtype=REC)
+    rec["pos_x"], rec["pos_y"], rec["rot"] = t.x[idx], t.y[idx], t.heading[idx]
+    orc.reset_agents(np.arange(N), t.x[idx], t.y[idx], t.heading[idx])
+    return t, dev, orc, rec, rng
+
+
+class Run:
+    """The device side runs its steps back to back (that is what makes the kernel stay); the oracle replays them afterwards."""
+
+    def __init__(self, gpu, oracle, t, dev, orc, rec, rng):
+        self.gpu, self.oracle, self.t, self.dev, self.orc, self.rec, self.rng = gpu, oracle, t, dev, orc, rec, rng
+        self.log = []
+
+    def steps(self, n, pause=0.0):
+        t, rec, N = self.t, self.rec, self.dev.N
+        thr = self.rng.uniform(30, 100, (n, N)).astype(np.float32)
+        steer = self.rng.uniform(-5, 5, (n, N)).astype(np.float32)
+        where = self.rng.integers(0, t.P, (n, N))
+        for i in range(n):
+            if pause:
+                time.sleep(pause)
+            crashed = np.flatnonzero(rec["crashed"])  # crashed agents are put back first, as the applications do
+            if crashed.size:
+                idx = where[i, crashed]
+                rec["pos_x"][crashed], rec["pos_y"][crashed], rec["rot"][crashed] = t.x[idx], t.y[idx], t.heading[idx]
+                rec["speed"][crashed] = rec["acc"][crashed] = 0
+                rec["crashed"][crashed] = rec["timed_out"][crashed] = 0
+            rec["throttle"], rec["steer"] = thr[i], steer[i]
+            hits = packed_step(self.gpu, self.dev, rec, WITH_STATS)
+            self.log.append((crashed, where[i, crashed], thr[i], steer[i], rec.copy(), hits))
+
+    def check(self):
+        """Replays every logged step on the oracle and compares all fields, bit for bit."""
+        t, orc, oracle = self.t, self.orc, self.oracle
+        for n, (crashed, idx, thr, steer, rec, hits) in enumerate(self.log):
+            if crashed.size:
+                orc.reset_agents(crashed, t.x[idx], t.y[idx], t.heading[idx])
+            orc.set(oracle.F_THR, thr)
+            orc.set(oracle.F_STEER, steer)
+            orc.step(1)
+            o = orc.snapshot()
+            for k, ok_ in ORACLE_KEYS.items():
+                a, b = np.ascontiguousarray(rec[k]), np.ascontiguousarray(o[ok_])
+                assert a.tobytes() == b.astype(a.dtype).tobytes(), (n, k)
+            assert np.array_equal(hits[..., 0].view(np.uint32), o["rel_x"].view(np.uint32)), n
+            assert np.array_equal(hits[..., 1].view(np.uint32), o["rel_y"].view(np.uint32)), n
+        done = len(self.log)
+        self.log = []
+        return done
+
+
+@pytest.mark.parametrize("N,R", [(1, 5), (15, 5), (50, 15), (64, 64)])
+def test_resident_steps_match_oracle(gpu, oracle, monkeypatch, N, R):
+    monkeypatch.setenv("OKENV_RESIDENT", "1")
+    run = Run(gpu, oracle, *make(gpu, oracle, N, R, seed=N))
+    assert run.dev.info()["agents_per_block"] == 1
+    run.steps(300)
+    info = run.dev.info()
+    assert info["packed_resident"] == 1 and info["packed_resident_steps"] >= 290 and info["packed_fallbacks"] == 0
+    assert run.dev.step_count == 300
+    assert run.check() == 300
+    run.dev.close()
+
+
+def test_resident_starts_by_itself_and_yields_to_other_calls(gpu, oracle, monkeypatch):
+    monkeypatch.delenv("OKENV_RESIDENT", raising=False)
+    run = Run(gpu, oracle, *make(gpu, oracle, 15, 5, track="Silverstone", seed=3))
+    dev = run.dev
+    run.steps(80)          # a tight loop: after 16 quick steps the kernel stays
+    assert dev.info()["packed_resident"] == 1 and dev.info()["packed_resident_steps"] > 20
+    run.check()
+    # any other call stops it first and sees the state of the last step
+    o = run.orc.snapshot()
+    assert np.array_equal(dev.get(gpu.capi.F_POS_X).view(np.uint32), o["pos_x"].view(np.uint32))
+    assert np.array_equal(np.asarray(dev.get(gpu.capi.F_HIT_X)).view(np.uint32).ravel(), o["hit_x"].view(np.uint32).ravel())
+    assert dev.info()["packed_resident"] == 0
+    run.steps(60)          # ... and comes back
+    assert dev.info()["packed_resident"] == 1
+    served = dev.info()["packed_resident_steps"]
+    time.sleep(0.005)      # longer than the kernel waits: it has left, the next step is a launch of its own
+    run.steps(1)
+    assert dev.info()["packed_resident"] == 0 and dev.info()["packed_resident_steps"] == served
+    run.steps(5, pause=0.001)   # slow steps never make it resident
+    assert dev.info()["packed_resident"] == 0 and dev.info()["packed_fallbacks"] == 0
+    assert run.check() == 66
+    dev.close()
+
+
+def test_resident_never_when_switched_off(gpu, oracle, monkeypatch):
+    monkeypatch.setenv("OKENV_RESIDENT", "0")
+    run = Run(gpu, oracle, *make(gpu, oracle, 15, 5, seed=5))
+    run.steps(60)
+    assert run.dev.info()["packed_resident"] == 0 and run.dev.info()["packed_resident_steps"] == 0
+    run.check()
+    run.dev.close()
+
+
+def test_step_handed_over_too_late_is_redone(gpu, oracle, monkeypatch):
+    monkeypatch.setenv("OKENV_RESIDENT", "1")
+    monkeypatch.setenv("OKENV_RESIDENT_STALL_US", "700")   # every seventh hand-over comes after the kernel's 300 us of patience
+    run = Run(gpu, oracle, *make(gpu, oracle, 15, 5, seed=9))
+    run.steps(80)
+    info = run.dev.info()
+    assert info["packed_fallbacks"] >= 5 and info["packed_resident_steps"] > info["packed_fallbacks"]
+    assert run.dev.step_count == 80
+    assert run.check() == 80
+    run.dev.close()
