@@ -919,7 +919,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
         // ---- phase 1: own ray over [0, T1] ----------------------------------------------------------
         bool  unfinished = false;
         float t_reached  = 0.F;
-        if (casts)
+        if (casts && phase1_range > 0.F)
         {
             const OkIntervalResult r1 =
                 ok_cast_poly_interval<false>(view, ox, oy, rdx, rdy, 0.F, phase1_range, nullptr, nullptr, nullptr OK_WPROF(0));
@@ -927,6 +927,8 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
             unfinished = !r1.conclusive;
             t_reached  = r1.t_reached;
         }
+        else
+            unfinished = casts; // no phase 1 (far more lanes than rays): phase 2 cuts the whole ray into intervals
         OK_STAMP(1);
         // ---- phase 2: the wave's unfinished rays, cut into m intervals each, over the wave's 64 lanes ------
         const unsigned long long pending = __ballot(unfinished);
