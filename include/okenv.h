@@ -232,7 +232,11 @@ typedef struct okenv_agent_record {
 #define OKENV_PACKED_COLLIDE_ONLY 2u /* CollisionChecker::checkCollision(): no kinematics, no standstill bookkeeping  */
 /* Upload `in[num_agents]`, run one Environment::step (or only the collision pass), download the new state into
  * `out[num_agents]` (may alias `in`) and Agent::sensor_hits_ as interleaved (x, y) pairs into sensor_hits_xy
- * [num_agents * num_rays * 2].  Host pointers; synchronises. */
+ * [num_agents * num_rays * 2].  Host pointers; synchronises.
+ * Up to 64 single-wave agents, OKENV_PACKED_WITH_STATS steps: when such calls follow each other within 100 us, a
+ * resident step kernel takes them over (no launch per step; okenv_info.packed_resident).  It leaves after 300 us
+ * without a step and before any other call on the handle does its work; results are the same bits either way.
+ * Environment variable OKENV_RESIDENT: 0 = never, 1 = from the first eligible call on. */
 OKENV_API int okenv_step_packed(okenv_t h, const okenv_agent_record *in, okenv_agent_record *out, float *sensor_hits_xy,
                                 uint32_t flags);
 
