@@ -750,311 +750,343 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
     if (kResident && __ballot(agent_ok) == 0ULL)
         return;
     uint32_t res_seq = p.done_seq; // the sequence number this wave waits for
-    for (;;) // (left at the bottom unless kResident)
+    for (;;) // one pass per step the resident form serves; every other form leaves at the bottom of the first
     {
-    if (kResident)
-    {
-        // The slot is one 64-byte line of the host's memory, fetched by ONE load of 16 lanes.  Words 3, 7, 11, 15 hold the
-        // sequence number, written by the host after the record words: a 16-byte piece of the line that shows the new number
-        // was read after its record words were written, whatever the pieces a PCIe read may be served in.
-        const int                lane = static_cast<int>(threadIdx.x) & 63;
-        const uint32_t          *slot = p.slots + static_cast<size_t>(a) * 16U;
-        const unsigned long long t0   = __builtin_amdgcn_s_memrealtime();
-        uint32_t                 w    = 0U;
-        bool                     go   = false;
-        for (;;)
+        if (kResident)
         {
-            w = (lane < 16) ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0U;
-            const uint32_t s0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w), 3));
-            const uint32_t s1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w), 7));
-            const uint32_t s2 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w), 11));
-            const uint32_t s3 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w), 15));
-            if (s0 == s1 && s1 == s2 && s2 == s3 && (s0 == res_seq || s0 == 0xFFFFFFFFU))
+            // The slot is one 64-byte line of the host's memory, fetched by ONE load of 16 lanes.  Words 3, 7, 11, 15 hold the
+            // sequence number, written by the host after the record words: a 16-byte piece of the line that shows the new number
+            // was read after its record words were written, whatever the pieces a PCIe read may be served in.
+            const int                lane = static_cast<int>(threadIdx.x) & 63;
+            const uint32_t          *slot = p.slots + static_cast<size_t>(a) * 16U;
+            const unsigned long long t0   = __builtin_amdgcn_s_memrealtime();
+            uint32_t                 w    = 0U;
+            bool                     go   = false;
+            for (;;)
             {
-                go = s0 == res_seq;
-                break;
+                w = (lane < 16) ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0U;
+                const uint32_t s0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w), 3));
+                const uint32_t s1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w), 7));
+                const uint32_t s2 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w), 11));
+                const uint32_t s3 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w), 15));
+                if (s0 == s1 && s1 == s2 && s2 == s3 && (s0 == res_seq || s0 == 0xFFFFFFFFU))
+                {
+                    go = s0 == res_seq;
+                    break;
+                }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > static_cast<unsigned long long>(p.idle_ticks))
+                    break; // nobody has asked for a step for a long time (or ever will: the process may be gone)
+                __builtin_amdgcn_s_sleep(2);
             }
-            if (__builtin_amdgcn_s_memrealtime() - t0 > static_cast<unsigned long long>(p.idle_ticks))
-                break; // nobody has asked for a step for a long time (or ever will: the process may be gone)
-            __builtin_amdgcn_s_sleep(2);
-        }
-        if (!go)
-            break;
-        uint32_t rw[sizeof(okenv_agent_record) / 4U];
+            if (!go)
+                break;
+            uint32_t rw[sizeof(okenv_agent_record) / 4U];
 #pragma unroll
-        for (unsigned j = 0; j < sizeof(okenv_agent_record) / 4U; ++j)
-            rw[j] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w), j + j / 3U));
-        __builtin_memcpy(&rc_in, rw, sizeof(okenv_agent_record));
-    }
-    if (kPacked)
-    { // the caller's Agent objects, as records in mapped host memory
-        const okenv_agent_record &rc = rc_in;
-        ag.pos_x                    = rc.pos_x;
-        ag.pos_y                    = rc.pos_y;
-        ag.rot                      = rc.rot;
-        ag.speed                    = rc.speed;
-        ag.acc                      = rc.acc;
-        ag.thr                      = rc.throttle;
-        ag.steer                    = rc.steer;
-        ag.mode                     = rc.mode;
-        ag.crashed                  = rc.crashed != 0;
-        ag.timed_out                = rc.timed_out != 0;
-        if (p.rec_with_stats)
-        {
-            ag.disp_x   = rc.disp_x;
-            ag.disp_y   = rc.disp_y;
-            ag.disp_ctr = rc.disp_ctr;
-            ag.disp_to  = rc.disp_timed_out != 0;
+            for (unsigned j = 0; j < sizeof(okenv_agent_record) / 4U; ++j)
+                rw[j] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w), j + j / 3U));
+            __builtin_memcpy(&rc_in, rw, sizeof(okenv_agent_record));
         }
-    }
-    float       last_rel_x = 0.F, last_rel_y = 0.F; // kPacked: sensor_hits_ of the last step
-    float       last_dist = (kPolicy != kPolicyNone && ray_ok) ? p.st.dist[k] : 0.F;
-    int         q_state = 0, q_action = 0, q_prev = 0;
-    float      *q_row0 = nullptr; // this agent's table
-    if (kPolicy == kPolicyQ)
-    {
-        q_state  = p.q_state[a];
-        q_action = p.q_action[a];
-        q_prev   = p.q_prev_idx[a];
-        q_row0   = p.q_table + static_cast<size_t>(a) * (OK_Q_STATES * OK_Q_ACTIONS);
-    }
-    // Q values of the agent's current state.  The table (47.8 MB at C5) lives in HBM / Infinity Cache and only this
-    // group ever touches this agent's part of it, so the row is read once per launch and then carried in registers:
-    // after a step it is either patched with the value just learned or replaced by the next state's row, which the
-    // update needs anyway.  One memory round trip per step instead of three; loads and stores stay agent-scope because
-    // lane 0 of the group writes what the others have read.
-    float qc0 = 0.F, qc1 = 0.F, qc2 = 0.F;
-    if (kPolicy == kPolicyQ)
-    {
-        const float *row = q_row0 + q_state * OK_Q_ACTIONS;
-        qc0              = __hip_atomic_load(row + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        qc1              = __hip_atomic_load(row + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        qc2              = __hip_atomic_load(row + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+        if (kPacked)
+        { // the caller's Agent objects, as records in mapped host memory
+            const okenv_agent_record &rc = rc_in;
+            ag.pos_x                    = rc.pos_x;
+            ag.pos_y                    = rc.pos_y;
+            ag.rot                      = rc.rot;
+            ag.speed                    = rc.speed;
+            ag.acc                      = rc.acc;
+            ag.thr                      = rc.throttle;
+            ag.steer                    = rc.steer;
+            ag.mode                     = rc.mode;
+            ag.crashed                  = rc.crashed != 0;
+            ag.timed_out                = rc.timed_out != 0;
+            if (p.rec_with_stats)
+            {
+                ag.disp_x   = rc.disp_x;
+                ag.disp_y   = rc.disp_y;
+                ag.disp_ctr = rc.disp_ctr;
+                ag.disp_to  = rc.disp_timed_out != 0;
+            }
+        }
+        float       last_rel_x = 0.F, last_rel_y = 0.F; // kPacked: sensor_hits_ of the last step
+        float       last_dist = (kPolicy != kPolicyNone && ray_ok) ? p.st.dist[k] : 0.F;
+        int         q_state = 0, q_action = 0, q_prev = 0;
+        float      *q_row0 = nullptr; // this agent's table
+        if (kPolicy == kPolicyQ)
+        {
+            q_state  = p.q_state[a];
+            q_action = p.q_action[a];
+            q_prev   = p.q_prev_idx[a];
+            q_row0   = p.q_table + static_cast<size_t>(a) * (OK_Q_STATES * OK_Q_ACTIONS);
+        }
+        // Q values of the agent's current state.  The table (47.8 MB at C5) lives in HBM / Infinity Cache and only this
+        // group ever touches this agent's part of it, so the row is read once per launch and then carried in registers:
+        // after a step it is either patched with the value just learned or replaced by the next state's row, which the
+        // update needs anyway.  One memory round trip per step instead of three; loads and stores stay agent-scope because
+        // lane 0 of the group writes what the others have read.
+        float qc0 = 0.F, qc1 = 0.F, qc2 = 0.F;
+        if (kPolicy == kPolicyQ)
+        {
+            const float *row = q_row0 + q_state * OK_Q_ACTIONS;
+            qc0              = __hip_atomic_load(row + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            qc1              = __hip_atomic_load(row + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            qc2              = __hip_atomic_load(row + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 
 #if defined(OKENV_STAMPS)
-    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long wprof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // walk-internal stamps: [0..4] phase 1, [5..9] phase 2
+        unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long wprof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // walk-internal stamps: [0..4] phase 1, [5..9] phase 2
 #define OK_STAMP(i)                                                                                                    \
-    do                                                                                                                 \
-    {                                                                                                                  \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                  \
-        acc[i] += now_ - last_;                                                                                        \
-        last_ = now_;                                                                                                  \
-    } while (0)
+        do                                                                                                                 \
+        {                                                                                                                  \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                  \
+            acc[i] += now_ - last_;                                                                                        \
+            last_ = now_;                                                                                                  \
+        } while (0)
 #define OK_WPROF(o) , wprof + (o)
-    unsigned long long last_ = __builtin_amdgcn_s_memtime();
-    acc[2]                   = __builtin_amdgcn_s_memrealtime(); // wave start / end on the chip-wide 100 MHz clock
+        unsigned long long last_ = __builtin_amdgcn_s_memtime();
+        acc[2]                   = __builtin_amdgcn_s_memrealtime(); // wave start / end on the chip-wide 100 MHz clock
 #else
 #define OK_STAMP(i)
 #define OK_WPROF(o)
 #endif
-    ok_random_action ra_blk{}; // bench driver: this lane's share of the current block of drawn actions
-    // waves without a single agent (small populations get workgroups of at least 256 lanes so that the image is staged
-    // quickly) have nothing to step
-    const int n_steps = (__ballot(agent_ok) != 0ULL) ? p.n_steps : 0;
-    for (int s = 0; s < n_steps; ++s)
-    {
+        ok_random_action ra_blk{}; // bench driver: this lane's share of the current block of drawn actions
+        // waves without a single agent (small populations get workgroups of at least 256 lanes so that the image is staged
+        // quickly) have nothing to step
+        const int n_steps = (__ballot(agent_ok) != 0ULL) ? p.n_steps : 0;
+        for (int s = 0; s < n_steps; ++s)
+        {
 #if OKENV_PRIO == 2
-        // A launch ends with its slowest wave, and a wave is slow for many steps in a row (its agent sits where rays are long).
-        // Waves of one SIMD share its issue slots: the further a wave lags behind the leader of its SIMD, the higher its
-        // issue priority.  Purely a scheduling hint: no effect on results.
-        {
-            uint32_t leader = 0U;
-            if ((threadIdx.x & 63U) == 0U)
-                leader = atomicMax(&lds_progress[my_simd], static_cast<uint32_t>(s));
-            leader          = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(leader)));
-            const int behind = static_cast<int>(leader) - s;
-            if (behind >= 3 * OKENV_PRIO_STEP)
-                __builtin_amdgcn_s_setprio(3);
-            else if (behind >= 2 * OKENV_PRIO_STEP)
-                __builtin_amdgcn_s_setprio(2);
-            else if (behind >= OKENV_PRIO_STEP)
-                __builtin_amdgcn_s_setprio(1);
-            else
-                __builtin_amdgcn_s_setprio(0);
-        }
+            // A launch ends with its slowest wave, and a wave is slow for many steps in a row (its agent sits where rays are long).
+            // Waves of one SIMD share its issue slots: the further a wave lags behind the leader of its SIMD, the higher its
+            // issue priority.  Purely a scheduling hint: no effect on results.
+            {
+                uint32_t leader = 0U;
+                if ((threadIdx.x & 63U) == 0U)
+                    leader = atomicMax(&lds_progress[my_simd], static_cast<uint32_t>(s));
+                leader          = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(leader)));
+                const int behind = static_cast<int>(leader) - s;
+                if (behind >= 3 * OKENV_PRIO_STEP)
+                    __builtin_amdgcn_s_setprio(3);
+                else if (behind >= 2 * OKENV_PRIO_STEP)
+                    __builtin_amdgcn_s_setprio(2);
+                else if (behind >= OKENV_PRIO_STEP)
+                    __builtin_amdgcn_s_setprio(1);
+                else
+                    __builtin_amdgcn_s_setprio(0);
+            }
 #endif
-        if (kPolicy == kPolicyMlp)
-            okPolicyAction(p, a, r, G, ag, last_dist, ray_ok);
-        if (kPolicy == kPolicyQ)
-        { // QLearnAgent::updateAction (QAgent.hpp:98-119) from the carried row of the current state
-            q_action = ok_q_choose_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s), p.q_epsilon,
-                                          qc0, qc1, qc2);
-            ok_q_action_values(q_action, &ag.thr, &ag.steer);
-        }
-        // Bench driver (kActionsPhiloxReset): an action depends on (seed, agent, step) only, so lane r of the agent's group
-        // draws the action of step s_blk + r and one Philox evaluation serves G steps; each step then fetches its own
-        // (same draws, same bits as one evaluation per step).
-        ok_random_action ra_now{};
-        bool             have_drawn = false;
-        if (kPolicy == kPolicyNone && p.action_source == kActionsPhiloxReset)
-        {
-            const int idx = s & (G - 1);
-            if (idx == 0)
-                ra_blk = ok_draw_random_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s + r));
-            if (G == 64)
-            { // one agent per wave: the source lane is wave-uniform
-                ra_now.throttle   = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ra_blk.throttle), idx));
-                ra_now.steer      = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ra_blk.steer), idx));
-                ra_now.reset_word = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ra_blk.reset_word), idx));
+            if (kPolicy == kPolicyMlp)
+                okPolicyAction(p, a, r, G, ag, last_dist, ray_ok);
+            if (kPolicy == kPolicyQ)
+            { // QLearnAgent::updateAction (QAgent.hpp:98-119) from the carried row of the current state
+                q_action = ok_q_choose_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s), p.q_epsilon,
+                                              qc0, qc1, qc2);
+                ok_q_action_values(q_action, &ag.thr, &ag.steer);
             }
-            else
+            // Bench driver (kActionsPhiloxReset): an action depends on (seed, agent, step) only, so lane r of the agent's group
+            // draws the action of step s_blk + r and one Philox evaluation serves G steps; each step then fetches its own
+            // (same draws, same bits as one evaluation per step).
+            ok_random_action ra_now{};
+            bool             have_drawn = false;
+            if (kPolicy == kPolicyNone && p.action_source == kActionsPhiloxReset)
             {
-                ra_now.throttle   = __shfl(ra_blk.throttle, idx, G);
-                ra_now.steer      = __shfl(ra_blk.steer, idx, G);
-                ra_now.reset_word = static_cast<uint32_t>(__shfl(static_cast<int>(ra_blk.reset_word), idx, G));
-            }
-            have_drawn = true;
-        }
-        float sr, cr;
-        float rdx = 1.F, rdy = 0.F;
-        okAgentPreStep(p, ag, a, s, sr, cr, ray_deg, &rdy, &rdx, have_drawn, ra_now);
-        const float ox     = ag.pos_x + p.sensor_offset * cr;
-        const float oy     = ag.pos_y + p.sensor_offset * sr;
-        const bool  casts  = ray_ok && !ag.crashed;
-
-        OK_STAMP(0);
-        float min_t = OK_SENSOR_RANGE; // the ray's first-hit parameter
-        // ---- phase 1: own ray over [0, T1] ----------------------------------------------------------
-        bool  unfinished = false;
-        float t_reached  = 0.F;
-        if (casts && phase1_range > 0.F)
-        {
-            const OkIntervalResult r1 =
-                ok_cast_poly_interval<false>(view, ox, oy, rdx, rdy, 0.F, phase1_range, nullptr, nullptr, nullptr OK_WPROF(0));
-            min_t      = r1.min_t;
-            unfinished = !r1.conclusive;
-            t_reached  = r1.t_reached;
-        }
-        else
-            unfinished = casts; // no phase 1 (far more lanes than rays): phase 2 cuts the whole ray into intervals
-        OK_STAMP(1);
-        // ---- phase 2: the wave's unfinished rays, cut into m intervals each, over the wave's 64 lanes ------
-        const unsigned long long pending = __ballot(unfinished);
-        if (pending != 0ULL)
-        {
-            const int lane = static_cast<int>(__lane_id());
-            const int n    = __popcll(pending);
-#if OKENV_PRIO == 1 // waves with much phase-2 work get issue priority
-            if (n > OKENV_PRIO_N2)
-                __builtin_amdgcn_s_setprio(2);
-            else if (n > OKENV_PRIO_N1)
-                __builtin_amdgcn_s_setprio(1);
-#endif
-            int       m    = 64 / n;
-            m              = m > kMaxSplit ? kMaxSplit : m;
-            // rank of an unfinished lane among the pending ones; rank -> lane through a forward permute
-            const int rank  = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pending >> 32),
-                                                                         __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pending), 0U)));
-            // (pending lanes go to slots 0..n-1 in lane order, the others fill n..63: a bijection, so no two lanes
-            // write the same slot)
-            const int owner_of_rank = __builtin_amdgcn_ds_permute((unfinished ? rank : n + (lane - rank)) << 2, lane);
-            // task of this lane: interval j of pending ray q
-            // (lane + 0.5) / m is never within 1/16 of an integer, so the approximate reciprocal cannot misplace the floor
-            const float inv_m = okRcpApprox(static_cast<float>(m));
-            const int   q     = static_cast<int>((static_cast<float>(lane) + 0.5F) * inv_m);
-            const int  j      = lane - q * m;
-            const bool has    = q < n;
-            const int  owner  = __shfl(owner_of_rank, has ? q : 0, 64);
-            const float tox   = __shfl(ox, owner, 64);
-            const float toy   = __shfl(oy, owner, 64);
-            const float tdx   = __shfl(rdx, owner, 64);
-            const float tdy   = __shfl(rdy, owner, 64);
-            const float t0    = __shfl(t_reached, owner, 64);
-            float       found = OK_SENSOR_RANGE;
-            if (has)
-            {
-                // neighbouring lanes evaluate the shared bound with the same expression, the last interval is open-ended:
-                // the intervals tile [t0, inf) whatever dt rounds to
-                const float dt = (OK_SENSOR_RANGE - t0) * inv_m;
-                const float ta = t0 + static_cast<float>(j) * dt;
-                const float tb = (j + 1 == m) ? OKRC_INF : t0 + static_cast<float>(j + 1) * dt;
-                const OkIntervalResult r2 = ok_cast_poly_interval<false>(view, tox, toy, tdx, tdy, ta, tb, nullptr, nullptr, nullptr OK_WPROF(5));
-                found                     = r2.min_t;
-            }
-            // min over the m lanes of a ray (consecutive lanes), then back to the owner
-            const int first = unfinished ? rank * m : 0;
-            float     mine  = OK_SENSOR_RANGE;
-            // (the owner gathering all m results in one round trip measured slower than this shuffle tree plus one pull)
-#pragma unroll
-            for (int off = 1; off < kMaxSplit; off <<= 1)
-            {
-                const float other = __shfl_down(found, off, 64);
-                if (j + off < m && other < found)
-                    found = other;
-            }
-            mine = __shfl(found, first, 64);
-            if (unfinished && mine < min_t)
-                min_t = mine;
-#if OKENV_PRIO == 1
-            __builtin_amdgcn_s_setprio(0);
-#endif
-        }
-        OK_STAMP(3);
-
-        // ---- hit point, transform, crash test (CollisionChecker.cu:69-70,144-172) -----------------------------------
-        float min_d2 = OK_SENSOR_RANGE * OK_SENSOR_RANGE;
-        if (ray_ok)
-        {
-            float hx, hy;
-            if (casts)
-            {
-                hx                = ox + min_t * rdx;
-                hy                = oy + min_t * rdy;
-                p.st.hit_x[k]     = hx;
-                p.st.hit_y[k]     = hy;
-            }
-            else
-            { // stale world hit point of a crashed agent
-                hx = p.st.hit_x[k];
-                hy = p.st.hit_y[k];
-            }
-            min_d2 = okRayEpilogue(p.st, k, hx, hy, ox, oy, sr, cr, last_dist, kPacked ? &last_rel_x : nullptr, kPacked ? &last_rel_y : nullptr);
-            min_d2 = (min_d2 < OK_SENSOR_RANGE * OK_SENSOR_RANGE) ? min_d2 : OK_SENSOR_RANGE * OK_SENSOR_RANGE;
-        }
-        min_d2 = okGroupMin(min_d2, G);
-        if (min_d2 < OK_CRASH_DIST2)
-            ag.crashed = true;
-        if (kPolicy == kPolicyQ)
-        { // q_racer_sim.cpp:171-182: next state, reward from the progress along the centre line, table update
-            int next_state = 0, mult = 1;
-#pragma unroll
-            for (int i = 0; i < 5; ++i)
-            {
-                next_state += ok_q_bin(__shfl(last_dist, p.q_ray[i], G)) * mult;
-                mult *= 3;
-            }
-            // RaceTrack::findNearestTrackIndexBruteForce.  The centre line is bucketed by grid cell: the agent's lanes look
-            // at the 3 x 3 cells around its position first; if the best point found there is closer than the block's
-            // nearest edge, no point outside can beat or tie it and the result is the brute-force argmin (strict '<' per
-            // lane over ascending indices, (distance, index) order across lanes: "lowest index wins").  Otherwise -- an
-            // agent far from the track -- the lanes stride over the whole centre line as before.
-            float best = 3.402823466e+38F;
-            int   bi   = 0x7FFFFFFF;
-            bool  done = false;
-            if (p.cl_start != nullptr)
-            {
-                const OkGridGeom &g  = p.geom;
-                const int         ci = static_cast<int>((ag.pos_x - g.x0) * g.inv_cell), cj = static_cast<int>((ag.pos_y - g.y0) * g.inv_cell);
-                if (ag.pos_x >= g.x0 && ag.pos_y >= g.y0 && ci < g.nx && cj < g.ny)
+                const int idx = s & (G - 1);
+                if (idx == 0)
+                    ra_blk = ok_draw_random_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s + r));
+                if (G == 64)
+                { // one agent per wave: the source lane is wave-uniform
+                    ra_now.throttle   = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ra_blk.throttle), idx));
+                    ra_now.steer      = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ra_blk.steer), idx));
+                    ra_now.reset_word = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ra_blk.reset_word), idx));
+                }
+                else
                 {
-                    for (int c = r; c < 9; c += G)
+                    ra_now.throttle   = __shfl(ra_blk.throttle, idx, G);
+                    ra_now.steer      = __shfl(ra_blk.steer, idx, G);
+                    ra_now.reset_word = static_cast<uint32_t>(__shfl(static_cast<int>(ra_blk.reset_word), idx, G));
+                }
+                have_drawn = true;
+            }
+            float sr, cr;
+            float rdx = 1.F, rdy = 0.F;
+            okAgentPreStep(p, ag, a, s, sr, cr, ray_deg, &rdy, &rdx, have_drawn, ra_now);
+            const float ox     = ag.pos_x + p.sensor_offset * cr;
+            const float oy     = ag.pos_y + p.sensor_offset * sr;
+            const bool  casts  = ray_ok && !ag.crashed;
+
+            OK_STAMP(0);
+            float min_t = OK_SENSOR_RANGE; // the ray's first-hit parameter
+            // ---- phase 1: own ray over [0, T1] ----------------------------------------------------------
+            bool  unfinished = false;
+            float t_reached  = 0.F;
+            if (casts && phase1_range > 0.F)
+            {
+                const OkIntervalResult r1 =
+                    ok_cast_poly_interval<false>(view, ox, oy, rdx, rdy, 0.F, phase1_range, nullptr, nullptr, nullptr OK_WPROF(0));
+                min_t      = r1.min_t;
+                unfinished = !r1.conclusive;
+                t_reached  = r1.t_reached;
+            }
+            else
+                unfinished = casts; // no phase 1 (far more lanes than rays): phase 2 cuts the whole ray into intervals
+            OK_STAMP(1);
+            // ---- phase 2: the wave's unfinished rays, cut into m intervals each, over the wave's 64 lanes ------
+            const unsigned long long pending = __ballot(unfinished);
+            if (pending != 0ULL)
+            {
+                const int lane = static_cast<int>(__lane_id());
+                const int n    = __popcll(pending);
+#if OKENV_PRIO == 1 // waves with much phase-2 work get issue priority
+                if (n > OKENV_PRIO_N2)
+                    __builtin_amdgcn_s_setprio(2);
+                else if (n > OKENV_PRIO_N1)
+                    __builtin_amdgcn_s_setprio(1);
+#endif
+                int       m    = 64 / n;
+                m              = m > kMaxSplit ? kMaxSplit : m;
+                // rank of an unfinished lane among the pending ones; rank -> lane through a forward permute
+                const int rank  = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pending >> 32),
+                                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pending), 0U)));
+                // (pending lanes go to slots 0..n-1 in lane order, the others fill n..63: a bijection, so no two lanes
+                // write the same slot)
+                const int owner_of_rank = __builtin_amdgcn_ds_permute((unfinished ? rank : n + (lane - rank)) << 2, lane);
+                // task of this lane: interval j of pending ray q
+                // (lane + 0.5) / m is never within 1/16 of an integer, so the approximate reciprocal cannot misplace the floor
+                const float inv_m = okRcpApprox(static_cast<float>(m));
+                const int   q     = static_cast<int>((static_cast<float>(lane) + 0.5F) * inv_m);
+                const int  j      = lane - q * m;
+                const bool has    = q < n;
+                const int  owner  = __shfl(owner_of_rank, has ? q : 0, 64);
+                const float tox   = __shfl(ox, owner, 64);
+                const float toy   = __shfl(oy, owner, 64);
+                const float tdx   = __shfl(rdx, owner, 64);
+                const float tdy   = __shfl(rdy, owner, 64);
+                const float t0    = __shfl(t_reached, owner, 64);
+                float       found = OK_SENSOR_RANGE;
+                if (has)
+                {
+                    // neighbouring lanes evaluate the shared bound with the same expression, the last interval is open-ended:
+                    // the intervals tile [t0, inf) whatever dt rounds to
+                    const float dt = (OK_SENSOR_RANGE - t0) * inv_m;
+                    const float ta = t0 + static_cast<float>(j) * dt;
+                    const float tb = (j + 1 == m) ? OKRC_INF : t0 + static_cast<float>(j + 1) * dt;
+                    const OkIntervalResult r2 = ok_cast_poly_interval<false>(view, tox, toy, tdx, tdy, ta, tb, nullptr, nullptr, nullptr OK_WPROF(5));
+                    found                     = r2.min_t;
+                }
+                // min over the m lanes of a ray (consecutive lanes), then back to the owner
+                const int first = unfinished ? rank * m : 0;
+                float     mine  = OK_SENSOR_RANGE;
+                // (the owner gathering all m results in one round trip measured slower than this shuffle tree plus one pull)
+#pragma unroll
+                for (int off = 1; off < kMaxSplit; off <<= 1)
+                {
+                    const float other = __shfl_down(found, off, 64);
+                    if (j + off < m && other < found)
+                        found = other;
+                }
+                mine = __shfl(found, first, 64);
+                if (unfinished && mine < min_t)
+                    min_t = mine;
+#if OKENV_PRIO == 1
+                __builtin_amdgcn_s_setprio(0);
+#endif
+            }
+            OK_STAMP(3);
+
+            // ---- hit point, transform, crash test (CollisionChecker.cu:69-70,144-172) -----------------------------------
+            float min_d2 = OK_SENSOR_RANGE * OK_SENSOR_RANGE;
+            if (ray_ok)
+            {
+                float hx, hy;
+                if (casts)
+                {
+                    hx                = ox + min_t * rdx;
+                    hy                = oy + min_t * rdy;
+                    p.st.hit_x[k]     = hx;
+                    p.st.hit_y[k]     = hy;
+                }
+                else
+                { // stale world hit point of a crashed agent
+                    hx = p.st.hit_x[k];
+                    hy = p.st.hit_y[k];
+                }
+                min_d2 = okRayEpilogue(p.st, k, hx, hy, ox, oy, sr, cr, last_dist, kPacked ? &last_rel_x : nullptr, kPacked ? &last_rel_y : nullptr);
+                min_d2 = (min_d2 < OK_SENSOR_RANGE * OK_SENSOR_RANGE) ? min_d2 : OK_SENSOR_RANGE * OK_SENSOR_RANGE;
+            }
+            min_d2 = okGroupMin(min_d2, G);
+            if (min_d2 < OK_CRASH_DIST2)
+                ag.crashed = true;
+            if (kPolicy == kPolicyQ)
+            { // q_racer_sim.cpp:171-182: next state, reward from the progress along the centre line, table update
+                int next_state = 0, mult = 1;
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+                {
+                    next_state += ok_q_bin(__shfl(last_dist, p.q_ray[i], G)) * mult;
+                    mult *= 3;
+                }
+                // RaceTrack::findNearestTrackIndexBruteForce.  The centre line is bucketed by grid cell: the agent's lanes look
+                // at the 3 x 3 cells around its position first; if the best point found there is closer than the block's
+                // nearest edge, no point outside can beat or tie it and the result is the brute-force argmin (strict '<' per
+                // lane over ascending indices, (distance, index) order across lanes: "lowest index wins").  Otherwise -- an
+                // agent far from the track -- the lanes stride over the whole centre line as before.
+                float best = 3.402823466e+38F;
+                int   bi   = 0x7FFFFFFF;
+                bool  done = false;
+                if (p.cl_start != nullptr)
+                {
+                    const OkGridGeom &g  = p.geom;
+                    const int         ci = static_cast<int>((ag.pos_x - g.x0) * g.inv_cell), cj = static_cast<int>((ag.pos_y - g.y0) * g.inv_cell);
+                    if (ag.pos_x >= g.x0 && ag.pos_y >= g.y0 && ci < g.nx && cj < g.ny)
                     {
-                        const int ix = ci + (c % 3) - 1, iy = cj + (c / 3) - 1;
-                        if (ix < 0 || iy < 0 || ix >= g.nx || iy >= g.ny)
-                            continue;
-                        const int cell = iy * g.nx + ix;
-                        for (int k = lds_cstart[cell]; k < lds_cstart[cell + 1]; ++k)
+                        for (int c = r; c < 9; c += G)
                         {
-                            const int   i  = lds_cidx[k];
-                            const float dx = ag.pos_x - lds_cx[i], dy = ag.pos_y - lds_cy[i];
-                            const float d2 = dx * dx + dy * dy;
-                            if (d2 < best)
+                            const int ix = ci + (c % 3) - 1, iy = cj + (c / 3) - 1;
+                            if (ix < 0 || iy < 0 || ix >= g.nx || iy >= g.ny)
+                                continue;
+                            const int cell = iy * g.nx + ix;
+                            for (int k = lds_cstart[cell]; k < lds_cstart[cell + 1]; ++k)
                             {
-                                best = d2;
-                                bi   = i;
+                                const int   i  = lds_cidx[k];
+                                const float dx = ag.pos_x - lds_cx[i], dy = ag.pos_y - lds_cy[i];
+                                const float d2 = dx * dx + dy * dy;
+                                if (d2 < best)
+                                {
+                                    best = d2;
+                                    bi   = i;
+                                }
                             }
+                        }
+                        for (int off = 1; off < G; off <<= 1)
+                        {
+                            const float ob = __shfl_xor(best, off, 64);
+                            const int   oi = __shfl_xor(bi, off, 64);
+                            if (ob < best || (ob == best && oi < bi))
+                            {
+                                best = ob;
+                                bi   = oi;
+                            }
+                        }
+                        // distance from the position to the nearest edge of the 3 x 3 block (>= one cell), minus slack for
+                        // the rounding of the cell arithmetic and of d2
+                        const float ex = fminf(ag.pos_x - (g.x0 + static_cast<float>(ci - 1) * g.cell), (g.x0 + static_cast<float>(ci + 2) * g.cell) - ag.pos_x);
+                        const float ey = fminf(ag.pos_y - (g.y0 + static_cast<float>(cj - 1) * g.cell), (g.y0 + static_cast<float>(cj + 2) * g.cell) - ag.pos_y);
+                        const float m  = fminf(ex, ey) - 0.05F;
+                        done           = bi != 0x7FFFFFFF && m > 0.F && best < m * m;
+                    }
+                }
+                if (!done)
+                {
+                    best = 3.402823466e+38F;
+                    bi   = 0x7FFFFFFF;
+                    for (int i = r; i < p.P; i += G)
+                    {
+                        const float dx = ag.pos_x - lds_cx[i], dy = ag.pos_y - lds_cy[i];
+                        const float d2 = dx * dx + dy * dy;
+                        if (d2 < best)
+                        {
+                            best = d2;
+                            bi   = i;
                         }
                     }
                     for (int off = 1; off < G; off <<= 1)
@@ -1067,151 +1099,119 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
                             bi   = oi;
                         }
                     }
-                    // distance from the position to the nearest edge of the 3 x 3 block (>= one cell), minus slack for
-                    // the rounding of the cell arithmetic and of d2
-                    const float ex = fminf(ag.pos_x - (g.x0 + static_cast<float>(ci - 1) * g.cell), (g.x0 + static_cast<float>(ci + 2) * g.cell) - ag.pos_x);
-                    const float ey = fminf(ag.pos_y - (g.y0 + static_cast<float>(cj - 1) * g.cell), (g.y0 + static_cast<float>(cj + 2) * g.cell) - ag.pos_y);
-                    const float m  = fminf(ex, ey) - 0.05F;
-                    done           = bi != 0x7FFFFFFF && m > 0.F && best < m * m;
                 }
-            }
-            if (!done)
-            {
-                best = 3.402823466e+38F;
-                bi   = 0x7FFFFFFF;
-                for (int i = r; i < p.P; i += G)
+                const int   nearest = (bi == 0x7FFFFFFF) ? 0 : bi;
+                const float reward  = ok_q_reward(ag.crashed ? 1 : 0, nearest, &q_prev, p.P);
+                const float *nrow   = q_row0 + next_state * OK_Q_ACTIONS;
+                const float  n0     = __hip_atomic_load(nrow + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float  n1     = __hip_atomic_load(nrow + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float  n2     = __hip_atomic_load(nrow + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                float        mq     = n0;
+                mq                  = (n1 > mq) ? n1 : mq;
+                mq                  = (n2 > mq) ? n2 : mq;
+                float *cell         = q_row0 + q_state * OK_Q_ACTIONS + q_action;
+                const float old_q   = (q_action == 0) ? qc0 : ((q_action == 1) ? qc1 : qc2);
+                const float new_q   = ok_q_learn(old_q, mq, reward);
+                if (agent_ok && r == 0)
+                    __hip_atomic_store(cell, new_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the row carried into the next step: the current one with the learned value, or the next state's
+                qc0 = (q_action == 0) ? new_q : qc0;
+                qc1 = (q_action == 1) ? new_q : qc1;
+                qc2 = (q_action == 2) ? new_q : qc2;
+                if (!ag.crashed)
                 {
-                    const float dx = ag.pos_x - lds_cx[i], dy = ag.pos_y - lds_cy[i];
-                    const float d2 = dx * dx + dy * dy;
-                    if (d2 < best)
+                    if (next_state != q_state)
                     {
-                        best = d2;
-                        bi   = i;
+                        qc0 = n0;
+                        qc1 = n1;
+                        qc2 = n2;
                     }
-                }
-                for (int off = 1; off < G; off <<= 1)
-                {
-                    const float ob = __shfl_xor(best, off, 64);
-                    const int   oi = __shfl_xor(bi, off, 64);
-                    if (ob < best || (ob == best && oi < bi))
-                    {
-                        best = ob;
-                        bi   = oi;
-                    }
+                    q_state = next_state;
                 }
             }
-            const int   nearest = (bi == 0x7FFFFFFF) ? 0 : bi;
-            const float reward  = ok_q_reward(ag.crashed ? 1 : 0, nearest, &q_prev, p.P);
-            const float *nrow   = q_row0 + next_state * OK_Q_ACTIONS;
-            const float  n0     = __hip_atomic_load(nrow + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float  n1     = __hip_atomic_load(nrow + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float  n2     = __hip_atomic_load(nrow + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            float        mq     = n0;
-            mq                  = (n1 > mq) ? n1 : mq;
-            mq                  = (n2 > mq) ? n2 : mq;
-            float *cell         = q_row0 + q_state * OK_Q_ACTIONS + q_action;
-            const float old_q   = (q_action == 0) ? qc0 : ((q_action == 1) ? qc1 : qc2);
-            const float new_q   = ok_q_learn(old_q, mq, reward);
-            if (agent_ok && r == 0)
-                __hip_atomic_store(cell, new_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // the row carried into the next step: the current one with the learned value, or the next state's
-            qc0 = (q_action == 0) ? new_q : qc0;
-            qc1 = (q_action == 1) ? new_q : qc1;
-            qc2 = (q_action == 2) ? new_q : qc2;
-            if (!ag.crashed)
-            {
-                if (next_state != q_state)
-                {
-                    qc0 = n0;
-                    qc1 = n1;
-                    qc2 = n2;
-                }
-                q_state = next_state;
-            }
+            OK_STAMP(5);
         }
-        OK_STAMP(5);
-    }
-    if (kPolicy == kPolicyQ && agent_ok && r == 0)
-    {
-        p.q_state[a]    = q_state;
-        p.q_action[a]   = q_action;
-        p.q_prev_idx[a] = q_prev;
-    }
+        if (kPolicy == kPolicyQ && agent_ok && r == 0)
+        {
+            p.q_state[a]    = q_state;
+            p.q_action[a]   = q_action;
+            p.q_prev_idx[a] = q_prev;
+        }
 #if defined(OKENV_STAMPS)
-    acc[4] = __builtin_amdgcn_s_memrealtime();
-    if ((threadIdx.x & 63) == 0)
-    { // diagnostic build only: per-wave cycle sums go to the (otherwise unused here) rel_x tail... a dedicated buffer
-        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(const_cast<uint32_t *>(p.g_refs32));
-        const long          w   = gl >> 6;
-        for (int i = 0; i < 6; ++i)
-            dbg[w * 16 + i] = acc[i];
-    }
-    { // walk-internal stamps of the lane that spent the longest inside the walks (its view has the fewest gaps)
-        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(const_cast<uint32_t *>(p.g_refs32));
-        const long          w   = gl >> 6;
-        unsigned long long  tot = 0;
-        for (int i = 0; i < 10; ++i)
-            tot += wprof[i];
-        unsigned long long best = tot;
-        for (int off = 1; off < 64; off <<= 1)
-        {
-            const unsigned long long o = __shfl_xor(best, off, 64);
-            best                       = o > best ? o : best;
+        acc[4] = __builtin_amdgcn_s_memrealtime();
+        if ((threadIdx.x & 63) == 0)
+        { // diagnostic build only: per-wave cycle sums go to the (otherwise unused here) rel_x tail... a dedicated buffer
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(const_cast<uint32_t *>(p.g_refs32));
+            const long          w   = gl >> 6;
+            for (int i = 0; i < 6; ++i)
+                dbg[w * 16 + i] = acc[i];
         }
-        if (tot == best)
+        { // walk-internal stamps of the lane that spent the longest inside the walks (its view has the fewest gaps)
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(const_cast<uint32_t *>(p.g_refs32));
+            const long          w   = gl >> 6;
+            unsigned long long  tot = 0;
             for (int i = 0; i < 10; ++i)
-                dbg[w * 16 + 6 + i] = wprof[i];
-    }
+                tot += wprof[i];
+            unsigned long long best = tot;
+            for (int off = 1; off < 64; off <<= 1)
+            {
+                const unsigned long long o = __shfl_xor(best, off, 64);
+                best                       = o > best ? o : best;
+            }
+            if (tot == best)
+                for (int i = 0; i < 10; ++i)
+                    dbg[w * 16 + 6 + i] = wprof[i];
+        }
 #endif
-    if (agent_ok && r == 0)
-        okStoreAgent(p.st, a, ag);
-    if (kPacked)
-    {
-        if (ray_ok)
-        {
-            p.hits_xy_out[2 * k]     = last_rel_x;
-            p.hits_xy_out[2 * k + 1] = last_rel_y;
-        }
         if (agent_ok && r == 0)
+            okStoreAgent(p.st, a, ag);
+        if (kPacked)
         {
-            okenv_agent_record rc;
-            rc.pos_x          = ag.pos_x;
-            rc.pos_y          = ag.pos_y;
-            rc.rot            = ag.rot;
-            rc.speed          = ag.speed;
-            rc.acc            = ag.acc;
-            rc.throttle       = ag.thr;
-            rc.steer          = ag.steer;
-            rc.disp_x         = ag.disp_x;
-            rc.disp_y         = ag.disp_y;
-            rc.disp_ctr       = ag.disp_ctr;
-            rc.mode           = static_cast<uint8_t>(ag.mode);
-            rc.crashed        = ag.crashed ? 1 : 0;
-            rc.timed_out      = ag.timed_out ? 1 : 0;
-            rc.disp_timed_out = ag.disp_to ? 1 : 0;
-            p.rec_out[a]      = rc;
+            if (ray_ok)
+            {
+                p.hits_xy_out[2 * k]     = last_rel_x;
+                p.hits_xy_out[2 * k + 1] = last_rel_y;
+            }
+            if (agent_ok && r == 0)
+            {
+                okenv_agent_record rc;
+                rc.pos_x          = ag.pos_x;
+                rc.pos_y          = ag.pos_y;
+                rc.rot            = ag.rot;
+                rc.speed          = ag.speed;
+                rc.acc            = ag.acc;
+                rc.throttle       = ag.thr;
+                rc.steer          = ag.steer;
+                rc.disp_x         = ag.disp_x;
+                rc.disp_y         = ag.disp_y;
+                rc.disp_ctr       = ag.disp_ctr;
+                rc.mode           = static_cast<uint8_t>(ag.mode);
+                rc.crashed        = ag.crashed ? 1 : 0;
+                rc.timed_out      = ag.timed_out ? 1 : 0;
+                rc.disp_timed_out = ag.disp_to ? 1 : 0;
+                p.rec_out[a]      = rc;
+            }
         }
-    }
-    if (!kResident)
-    {
-        okFinishLaunch(p);
-        break;
-    }
-    // resident: this wave is all that is left of its workgroup.  Its results have left the device before it reports in; the
-    // last workgroup to do so answers the host (which asks for the next step only after that, so one counter is enough).
-    __threadfence_system();
-    if ((threadIdx.x & 63U) == 0U)
-    {
-        __threadfence();
-        if (atomicAdd(&p.step_counter[1], 1U) == gridDim.x - 1U)
+        if (!kResident)
         {
-            p.step_counter[1] = 0U;
-            __threadfence_system();
-            __hip_atomic_store(p.done_flag, res_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            okFinishLaunch(p);
+            break;
         }
+        // resident: this wave is all that is left of its workgroup.  Its results have left the device before it reports in; the
+        // last workgroup to do so answers the host (which asks for the next step only after that, so one counter is enough).
+        __threadfence_system();
+        if ((threadIdx.x & 63U) == 0U)
+        {
+            __threadfence();
+            if (atomicAdd(&p.step_counter[1], 1U) == gridDim.x - 1U)
+            {
+                p.step_counter[1] = 0U;
+                __threadfence_system();
+                __hip_atomic_store(p.done_flag, res_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        res_seq = okNextPackedSeq(res_seq);
     }
-    res_seq = okNextPackedSeq(res_seq);
-    } // for (;;)
 }
 
 // ---- small service kernels ------------------------------------------------------------------------------
