@@ -1186,9 +1186,11 @@ extern "C"
             // steps that follow each other closely are served by a resident kernel (see startResident)
             const auto   t_in  = std::chrono::steady_clock::now();
             const bool   quick = h->packed_seq != 0U && std::chrono::duration<double, std::micro>(t_in - h->packed_last_end).count() < kResidentGapUs;
-            h->packed_streak   = quick ? h->packed_streak + 1 : 0;
             const bool eligible = h->resident_mode != 0 && h->agents_per_block == 1 && h->N <= kResidentMaxAgents && h->own_stream && !h->timing &&
                                   (h->reset_flags & kAutoResetOn) == 0U && flags == OKENV_PACKED_WITH_STATS;
+            // (a run of quick steps counts only while every one of them is of the kind the resident kernel serves: a caller that
+            // alternates step() and checkCollision() must not start and stop a kernel on every other call)
+            h->packed_streak = (quick && eligible) ? h->packed_streak + 1 : 0;
             if (h->resident && (!eligible || !quick))
             { // too long since the last step (the kernel may have left by itself), or a kind of step it does not serve
                 const int src = stopResident(h);

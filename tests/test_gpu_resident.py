@@ -127,3 +127,17 @@ def test_step_handed_over_too_late_is_redone(gpu, oracle, monkeypatch):
     assert run.dev.step_count == 80
     assert run.check() == 80
     run.dev.close()
+
+
+def test_mixed_calls_do_not_start_and_stop_a_kernel_each_time(gpu, oracle, monkeypatch):
+    """step() and checkCollision() in turn: the collision-only pass is not served by the resident kernel, so none is started."""
+    from test_gpu_packed_step import COLLIDE_ONLY
+    monkeypatch.delenv("OKENV_RESIDENT", raising=False)
+    run = Run(gpu, oracle, *make(gpu, oracle, 15, 5, seed=11))
+    for _ in range(40):
+        run.steps(1)
+        packed_step(gpu, run.dev, run.rec.copy(), COLLIDE_ONLY)
+    info = run.dev.info()
+    assert info["packed_resident"] == 0 and info["packed_resident_steps"] == 0
+    assert run.check() == 40
+    run.dev.close()
