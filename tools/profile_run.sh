@@ -9,6 +9,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 1000 --warmup 100 --steps-per-launch 100 --repeats 3 --no-cpu-baseline --headline-only"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats_bench.json 2> $OUT/stats.log
+# the command the driver runs (one 20-step launch per timed region, 30 regions)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_k20 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --headline-only > $OUT/stats_k20_bench.json 2> $OUT/stats_k20.log
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM" \
@@ -29,6 +31,14 @@ for f in glob.glob(out + "/stats/*/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         if "okStepCoopKernel" in r["Name"]:
             avg_ns = float(r["AverageNs"])
+for f in glob.glob(out + "/stats_k20/*/*kernel_stats.csv"):
+    lines.append("== kernel stats of bench.py --steps 20 --warmup 5 (the command the driver runs; 20 steps per launch) ==")
+    lines += [l.rstrip() for l in open(f)]
+try:
+    lines.append("== bench line of that pass ==")
+    lines.append(open(out + "/stats_k20_bench.json").read().strip())
+except Exception as e:
+    lines.append(str(e))
 agg = collections.defaultdict(float); n = collections.defaultdict(int)
 for f in glob.glob(out + "/pmc*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
