@@ -97,6 +97,8 @@ struct okenv
     int         resident_steps{0}, resident_fallbacks{0}; // statistics (okenv_get_info)
     int         resident_stall_us{0}; // OKENV_RESIDENT_STALL_US, fault injection for the tests: the host dawdles this long before
                                       // it hands a step to the resident kernel, which has left by then
+    int         resident_need{16};  // quick steps in a row that start it: kResidentStreak, more after residencies that ended early
+    int         resident_served_now{0}; // steps the current residency has served
     int         packed_streak{0};   // packed steps in a row that came within kResidentGapUs of the one before
     std::chrono::steady_clock::time_point packed_last_end{};
     size_t      stage_done_off{0}, stage_slots_off{0};
@@ -363,6 +365,7 @@ int buildCenterlineBuckets(okenv *h)
 constexpr uint32_t kResidentIdleTicks = 30000U; // 100 MHz ticks: 300 us
 constexpr double   kResidentGapUs     = 100.0;  // the host treats the kernel as gone after this long without a step
 constexpr int      kResidentStreak    = 16;     // quick steps in a row before the kernel is made resident
+constexpr int      kResidentShort     = 32;     // a residency that served fewer steps than this quadruples that number
 constexpr uint32_t kResidentExit      = 0xFFFFFFFFU;
 constexpr int      kResidentMaxAgents = 64;
 
@@ -377,6 +380,10 @@ int stopResident(okenv *h)
     std::atomic_thread_fence(std::memory_order_seq_cst);
     h->resident      = false;
     h->packed_streak = 0;
+    // A residency that ends after a few steps was not worth its start and stop -- and a caller that waits for the whole
+    // device between its steps (hipDeviceSynchronize) sits out the kernel's idle time whenever one is resident: back off.
+    h->resident_need       = h->resident_served_now < kResidentShort ? std::min(h->resident_need * 4, 1 << 20) : kResidentStreak;
+    h->resident_served_now = 0;
     OK_HIP(h, hipStreamSynchronize(h->resident_stream));
     // a step the kernel left half done (it timed out between two workgroups) may have left the finish counter behind
     OK_HIP(h, hipMemsetAsync(h->d_step_count + 1, 0, sizeof(uint32_t), h->stream));
@@ -1198,7 +1205,7 @@ extern "C"
                     return src;
             }
             const bool was_resident = h->resident;
-            if (!h->resident && eligible && (h->resident_mode == 1 || h->packed_streak >= kResidentStreak))
+            if (!h->resident && eligible && (h->resident_mode == 1 || h->packed_streak >= h->resident_need))
             {
                 p.slots          = reinterpret_cast<const uint32_t *>(hm + slots_off);
                 p.idle_ticks     = kResidentIdleTicks;
@@ -1249,6 +1256,7 @@ extern "C"
                 }
                 std::atomic_thread_fence(std::memory_order_acquire);
                 ++h->resident_steps;
+                ++h->resident_served_now;
                 if (answered)
                     served = true;
                 else

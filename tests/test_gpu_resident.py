@@ -141,3 +141,17 @@ def test_mixed_calls_do_not_start_and_stop_a_kernel_each_time(gpu, oracle, monke
     assert info["packed_resident"] == 0 and info["packed_resident_steps"] == 0
     assert run.check() == 40
     run.dev.close()
+
+
+def test_short_residencies_back_off(gpu, oracle, monkeypatch):
+    """A caller that interrupts every run of quick steps soon after the kernel has become resident gets it less and less often
+    (the number of quick steps needed quadruples after a residency that served fewer than 32)."""
+    monkeypatch.delenv("OKENV_RESIDENT", raising=False)
+    run = Run(gpu, oracle, *make(gpu, oracle, 15, 5, seed=13))
+    for _ in range(12):
+        run.steps(20)
+        run.dev.get(gpu.capi.F_POS_X)   # stops a resident kernel
+    served = run.dev.info()["packed_resident_steps"]
+    assert 1 <= served <= 30            # without the back-off: four steps of every run of 20, i.e. 48
+    assert run.check() == 240
+    run.dev.close()
