@@ -1250,9 +1250,13 @@ extern "C"
                     }
                     // (a kernel launched a moment ago may still be on its way -- the first launch of a process loads the code
                     // object -- and its patience only starts when it does)
-                    if (!answered && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_asked).count() >
-                                         (just_started ? 50000.0 : 2.5 * kResidentGapUs))
+                    if (answered)
                         break;
+                    const double waited_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_asked).count();
+                    if (waited_us > (just_started ? 2.0e6 : 2.5 * kResidentGapUs))
+                        break;
+                    if (just_started && waited_us > 1000.0 && hipStreamQuery(h->resident_stream) != hipErrorNotReady)
+                        break; // its stream has drained (or failed): nobody is going to answer
                 }
                 std::atomic_thread_fence(std::memory_order_acquire);
                 ++h->resident_steps;
