@@ -233,17 +233,30 @@ OK_HD float ok_normalize_angle_deg(float angle)
     return angle;
 }
 
-/* GeneticAgent::updateAction's decode (EvolutionaryRacer/GeneticAgent.hpp:45-54) from the six pre-activations z:
- * sigmoid(z) > 0.5 is taken as z > 0 (they differ only for 0 < z < ~6e-8, where fp32 sigmoid rounds to exactly 0.5). */
+/* nn_output > kOutputActivationLim (GeneticAgent.hpp:45-54) on a PRE-activation z, where nn_output = sigmoid(z) =
+ * 1.F / (1.F + exp(-z)) in fp32 (Network.hpp:162-165).  The quotient exceeds 0.5 exactly when the rounded sum 1 + exp(-z)
+ * is below 2, i.e. when exp(-z) rounds to 1 - 2^-23 or less, i.e. when exp(-z) <= 1 - 1.5 * 2^-24 (the tie goes to the even
+ * neighbour, 1 - 2^-23), i.e. when z >= -ln(1 - 1.5 * 2^-24) = 1.5 * 2^-24 + 4.0e-15: the first float at or above that is
+ * 0x33C00001.  So the test is one comparison, with the bits of an fp32 sigmoid whose exp is correctly rounded there (glibc's
+ * expf is: tests/test_math.py compares the two over every float around the threshold).  For 0 < z < 8.94e-8 the sigmoid is
+ * exactly 0.5 and the output is NOT active. */
+OK_HD int ok_sigmoid_above_half(const float z)
+{
+    union { uint32_t u; float f; } t;
+    t.u = 0x33C00001u;
+    return z >= t.f; /* false for NaN, like the comparison with the sigmoid */
+}
+
+/* GeneticAgent::updateAction's decode (EvolutionaryRacer/GeneticAgent.hpp:45-54) from the six pre-activations z. */
 OK_HD void ok_ga_decode_action(const float z[OK_MLP_OUT], float *throttle, float *steer)
 {
     float t = 0.0f, s = 0.0f;
-    t += (z[0] > 0.0f) ? 0.3f : 0.0f;
-    t += (z[1] > 0.0f) ? -0.3f : 0.0f;
-    s += (z[2] > 0.0f) ? 1.0f : 0.0f;
-    s += (z[3] > 0.0f) ? 4.0f : 0.0f;
-    s += (z[4] > 0.0f) ? -1.0f : 0.0f;
-    s += (z[5] > 0.0f) ? -4.0f : 0.0f;
+    t += ok_sigmoid_above_half(z[0]) ? 0.3f : 0.0f;
+    t += ok_sigmoid_above_half(z[1]) ? -0.3f : 0.0f;
+    s += ok_sigmoid_above_half(z[2]) ? 1.0f : 0.0f;
+    s += ok_sigmoid_above_half(z[3]) ? 4.0f : 0.0f;
+    s += ok_sigmoid_above_half(z[4]) ? -1.0f : 0.0f;
+    s += ok_sigmoid_above_half(z[5]) ? -4.0f : 0.0f;
     *throttle = t;
     *steer = s;
 }

@@ -834,21 +834,36 @@ static float ga_normalize_angle_deg(float angle)
     return angle;
 }
 
-/* GeneticAgent::updateAction's Sigmoid branch (EvolutionaryRacer/GeneticAgent.hpp:45-54) on the six PRE-activations:
- * nn_output_[k] = sigmoid(z[k]) > kOutputActivationLim (0.5) holds exactly when z[k] > 0, except for 0 < z < ~6e-8 where
- * the fp32 sigmoid rounds to 0.5 (documented deviation).  kAccelerationDelta 0.3, kSteeringDeltaLow 1,
- * kSteeringDeltaHigh 4 (GeneticAgent.hpp:19-24). */
+/* Network::sigmoid (EvolutionaryRacer/Network.hpp:162-165): 1.F / (1.F + exp(-x)) in fp32, written out with glibc's expf
+ * (the reference's is Eigen's array exp, version unpinned). */
+static float ga_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+/* GeneticAgent::updateAction's Sigmoid branch (EvolutionaryRacer/GeneticAgent.hpp:45-54): an output is active when
+ * nn_output_[k] > kOutputActivationLim (0.5).  kAccelerationDelta 0.3, kSteeringDeltaLow 1, kSteeringDeltaHigh 4
+ * (GeneticAgent.hpp:19-24). */
 static void ga_decode_outputs(const float z[6], float *throttle_delta_out, float *steering_delta_out)
 {
+    float nn_output[6];
+    for (int k = 0; k < 6; ++k) nn_output[k] = ga_sigmoid(z[k]);
     float throttle_delta = 0.0f, steering_delta = 0.0f;
-    throttle_delta += (z[0] > 0.0f) ? 0.3f : 0.0f;
-    throttle_delta += (z[1] > 0.0f) ? -0.3f : 0.0f;
-    steering_delta += (z[2] > 0.0f) ? 1.0f : 0.0f;  /* left soft  */
-    steering_delta += (z[3] > 0.0f) ? 4.0f : 0.0f;  /* left hard  */
-    steering_delta += (z[4] > 0.0f) ? -1.0f : 0.0f; /* right soft */
-    steering_delta += (z[5] > 0.0f) ? -4.0f : 0.0f; /* right hard */
+    throttle_delta += (nn_output[0] > 0.5f) ? 0.3f : 0.0f;
+    throttle_delta += (nn_output[1] > 0.5f) ? -0.3f : 0.0f;
+    steering_delta += (nn_output[2] > 0.5f) ? 1.0f : 0.0f;  /* left soft  */
+    steering_delta += (nn_output[3] > 0.5f) ? 4.0f : 0.0f;  /* left hard  */
+    steering_delta += (nn_output[4] > 0.5f) ? -1.0f : 0.0f; /* right soft */
+    steering_delta += (nn_output[5] > 0.5f) ? -4.0f : 0.0f; /* right hard */
     *throttle_delta_out = throttle_delta;
     *steering_delta_out = steering_delta;
+}
+
+/* For tests/test_math.py: the decode as the oracle does it (sigmoid written out) and as the product's header does it (one
+ * comparison, include/okenv_math.h), on n sextuples of pre-activations. */
+ORACLE_API void oracle_ga_decode(const float *z, int n, float *thr_oracle, float *steer_oracle, float *thr_product, float *steer_product)
+{
+    for (int i = 0; i < n; ++i) {
+        ga_decode_outputs(z + 6 * (size_t)i, thr_oracle + i, steer_oracle + i);
+        ok_ga_decode_action(z + 6 * (size_t)i, thr_product + i, steer_product + i);
+    }
 }
 
 /* std::discrete_distribution over the parents' scores (EvolutionaryRacer/Mating.hpp:135-137) driven by one uniform draw:

@@ -73,3 +73,29 @@ def test_philox_known_answers(oracle):
         st = np.float32(r[1] >> 8) * np.float32(2.0 ** -24) * np.float32(10.0) - np.float32(5.0)
         assert np.float32(thr.value) == t and np.float32(steer.value) == st and word.value == r[2]
         assert 0.0 <= thr.value < 100.0 and -5.0 <= steer.value < 5.0
+
+
+def test_ga_output_threshold_equals_the_written_out_sigmoid(oracle):
+    """GeneticAgent's `sigmoid(z) > 0.5`: the product decides it with one comparison (z >= 0x33C00001, okenv_math.h), the oracle
+    evaluates 1 / (1 + expf(-z)) as Network.hpp:162-165 writes it.  Same decision for every float within 2^20 ulps of the
+    threshold, for every binade, for the special values and for a random sample; and the threshold is where the header says."""
+    thr_bits = 0x33C00001
+    near = (thr_bits + np.arange(-(1 << 20), (1 << 20), dtype=np.int64)).astype(np.uint32).view(np.float32)
+    binades = np.array([s * 2.0 ** e * m for e in range(-149, 128) for m in (1.0, 1.5, 1.9999999) for s in (1, -1)], dtype=np.float64)
+    rng = np.random.default_rng(3)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 8.94e-8, 8.9407e-8, 1.2e-7, 6e-8, 1e-7], dtype=np.float32)
+    z1 = np.concatenate([near, binades.astype(np.float32), special, rng.normal(0, 1, 200000).astype(np.float32),
+                         rng.normal(0, 1e-7, 200000).astype(np.float32)])
+    z1 = z1[: (z1.size // 6) * 6]
+    z = np.ascontiguousarray(z1.reshape(-1, 6))
+    n = z.shape[0]
+    to, so, tp, sp = (np.zeros(n, dtype=np.float32) for _ in range(4))
+    O.lib().oracle_ga_decode(z, n, to, so, tp, sp)
+    assert np.array_equal(to.view(np.uint32), tp.view(np.uint32)) and np.array_equal(so.view(np.uint32), sp.view(np.uint32))
+    # the threshold itself, output 3 (steer +4) alone
+    probe = np.zeros((3, 6), dtype=np.float32)
+    probe[:, 3] = np.array([thr_bits - 1, thr_bits, thr_bits + 1], dtype=np.uint32).view(np.float32)
+    probe[:, [0, 1, 2, 4, 5]] = -1.0
+    to, so, tp, sp = (np.zeros(3, dtype=np.float32) for _ in range(4))
+    O.lib().oracle_ga_decode(probe, 3, to, so, tp, sp)
+    assert so.tolist() == [0.0, 4.0, 4.0] and sp.tolist() == [0.0, 4.0, 4.0]
