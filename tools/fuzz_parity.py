@@ -30,7 +30,7 @@ while time.time() - t0 < budget:
         fan = rng.permutation(fan).astype(np.float32)
     mode = int(rng.integers(0, 2))
     cell = float(rng.choice([0.0, 0.0, 9.0, 14.0, 33.0]))
-    for key, choices in (("OKENV_LANES_PER_AGENT", [None, None, "8", "64"]), ("OKENV_PHASE1_RANGE", [None, None, "2", "20", "90"])):
+    for key, choices in (("OKENV_LANES_PER_AGENT", [None, None, "8", "64"]), ("OKENV_PHASE1_RANGE", [None, None, "0", "2", "20", "90"]), ("OKENV_AGENTS_PER_BLOCK", [None, None, "0", "1", "2"])):
         v = choices[int(rng.integers(0, len(choices)))]
         if v is None or (key == "OKENV_LANES_PER_AGENT" and int(v) < R and R > 64):
             os.environ.pop(key, None)
