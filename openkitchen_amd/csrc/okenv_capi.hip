@@ -428,6 +428,65 @@ int startResident(okenv *h, OkStepParams p, volatile uint32_t *slots)
     return OKENV_OK;
 }
 
+// One step through the resident kernel: the records go into the agents' slots, the sequence number after them; then the
+// host waits for the completion word.  *served is false when nobody answered (the kernel had left: idle for too long, e.g.
+// because this thread was descheduled): the kernel is drained and the caller redoes the step with a launch of its own, which
+// works from the same input records.
+int stepResident(okenv *h, const okenv_agent_record *in, volatile uint32_t *slots, const volatile uint32_t *done_word, const bool just_started,
+                 bool *served)
+{
+    if (h->resident_stall_us > 0 && h->resident_steps % 7 == 6)
+    { // (tests only) every seventh resident step comes too late
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(h->resident_stall_us);
+        while (std::chrono::steady_clock::now() < until)
+        {
+        }
+    }
+    const uint32_t seq = nextPackedSeq(h);
+    const size_t   N   = static_cast<size_t>(h->N);
+    for (size_t i = 0; i < N; ++i)
+    { // record word j goes to slot word j + j / 3: words 3, 7, 11, 15 of a slot carry the sequence number
+        uint32_t w[sizeof(okenv_agent_record) / 4U];
+        std::memcpy(w, &in[i], sizeof(okenv_agent_record));
+        for (unsigned j = 0; j < sizeof(okenv_agent_record) / 4U; ++j)
+            slots[16U * i + j + j / 3U] = w[j];
+    }
+    std::atomic_thread_fence(std::memory_order_release); // records before sequence numbers (and x86 keeps store order)
+    for (size_t i = 0; i < N; ++i)
+        for (unsigned q = 3; q < 16U; q += 4U)
+            slots[16U * i + q] = seq;
+    bool       answered = false;
+    const auto t_asked  = std::chrono::steady_clock::now();
+    while (!answered)
+    {
+        for (int spin = 0; spin < 1024 && !answered; ++spin)
+        {
+            answered = *done_word == seq;
+            if (!answered)
+                __builtin_ia32_pause();
+        }
+        if (answered)
+            break;
+        // (a kernel launched a moment ago may still be on its way -- the first launch of a process loads the code object -- and
+        // its patience only starts when it does)
+        const double waited_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_asked).count();
+        if (waited_us > (just_started ? 2.0e6 : 2.5 * kResidentGapUs))
+            break;
+        if (just_started && waited_us > 1000.0 && hipStreamQuery(h->resident_stream) != hipErrorNotReady)
+            break; // its stream has drained (or failed): nobody is going to answer
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    ++h->resident_steps;
+    ++h->resident_served_now;
+    *served = answered;
+    if (!answered)
+    {
+        ++h->resident_fallbacks;
+        return stopResident(h);
+    }
+    return OKENV_OK;
+}
+
 // okenv_step_packed: the step kernel's last workgroup stores the launch's sequence number into mapped host memory once all
 // results are there.  Spinning on that word returns about 5 us earlier than hipStreamSynchronize (which waits for the
 // queue's completion signal: 10.9 us against 6.0 us for an empty kernel on this machine).  The stream is asked now and
@@ -1214,62 +1273,11 @@ extern "C"
                     return src;
             }
             bool served = false;
-            const bool just_started = !was_resident && h->resident;
             if (h->resident)
             {
-                if (h->resident_stall_us > 0 && h->resident_steps % 7 == 6)
-                { // (tests only) every seventh resident step comes too late
-                    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(h->resident_stall_us);
-                    while (std::chrono::steady_clock::now() < until)
-                    {
-                    }
-                }
-                const uint32_t     seq   = nextPackedSeq(h);
-                volatile uint32_t *slots = reinterpret_cast<volatile uint32_t *>(hs + slots_off);
-                for (size_t i = 0; i < N; ++i)
-                { // record word j goes to slot word j + j / 3: words 3, 7, 11, 15 of a slot carry the sequence number
-                    uint32_t w[sizeof(okenv_agent_record) / 4U];
-                    std::memcpy(w, &in[i], sizeof(okenv_agent_record));
-                    for (unsigned j = 0; j < sizeof(okenv_agent_record) / 4U; ++j)
-                        slots[16U * i + j + j / 3U] = w[j];
-                }
-                std::atomic_thread_fence(std::memory_order_release); // records before sequence numbers (and x86 keeps store order)
-                for (size_t i = 0; i < N; ++i)
-                    for (unsigned q = 3; q < 16U; q += 4U)
-                        slots[16U * i + q] = seq;
-                // wait for the answer; a kernel that has left (idle for too long, e.g. this thread was descheduled) never answers
-                bool       answered = false;
-                const auto t_asked  = std::chrono::steady_clock::now();
-                while (!answered)
-                {
-                    for (int spin = 0; spin < 1024 && !answered; ++spin)
-                    {
-                        answered = *done_word == seq;
-                        if (!answered)
-                            __builtin_ia32_pause();
-                    }
-                    // (a kernel launched a moment ago may still be on its way -- the first launch of a process loads the code
-                    // object -- and its patience only starts when it does)
-                    if (answered)
-                        break;
-                    const double waited_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_asked).count();
-                    if (waited_us > (just_started ? 2.0e6 : 2.5 * kResidentGapUs))
-                        break;
-                    if (just_started && waited_us > 1000.0 && hipStreamQuery(h->resident_stream) != hipErrorNotReady)
-                        break; // its stream has drained (or failed): nobody is going to answer
-                }
-                std::atomic_thread_fence(std::memory_order_acquire);
-                ++h->resident_steps;
-                ++h->resident_served_now;
-                if (answered)
-                    served = true;
-                else
-                { // fall back to a launch of its own for this step: it works from the same input records
-                    ++h->resident_fallbacks;
-                    const int src = stopResident(h);
-                    if (src != OKENV_OK)
-                        return src;
-                }
+                const int src = stepResident(h, in, reinterpret_cast<volatile uint32_t *>(hs + slots_off), done_word, !was_resident, &served);
+                if (src != OKENV_OK)
+                    return src;
             }
             if (!served)
             {
