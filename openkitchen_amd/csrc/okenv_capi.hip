@@ -411,6 +411,14 @@ uint32_t nextPackedSeq(okenv *h)
 
 size_t coopLdsBytes(const okenv *h);
 
+// Policy-free launches of a population with spare lanes and no phase 1 use the kernel's direct dealing of intervals to lanes
+// (okStepCoopKernel's kDirect).
+bool directIntervals(const okenv *h)
+{
+    return h->phase1_range <= 0.F && h->G >= 2 * h->R;
+}
+
+
 // Starts the resident kernel on a stream of its own; `p` carries the exchange pointers of okenv_step_packed.
 int startResident(okenv *h, OkStepParams p, volatile uint32_t *slots)
 {
@@ -421,8 +429,12 @@ int startResident(okenv *h, OkStepParams p, volatile uint32_t *slots)
         slots[i] = 0U;
     std::atomic_thread_fence(std::memory_order_seq_cst);
     p.done_seq = okNextPackedSeq(h->packed_seq); // the first number the kernel waits for
-    hipLaunchKernelGGL((okStepCoopKernel<kPolicyNone, true, true>), dim3(h->grid_blocks), dim3(h->block_threads), coopLdsBytes(h), h->resident_stream,
-                       p, static_cast<uint32_t>(h->image_bytes), h->phase1_range);
+    if (directIntervals(h))
+        hipLaunchKernelGGL((okStepCoopKernel<kPolicyNone, true, true, true>), dim3(h->grid_blocks), dim3(h->block_threads), coopLdsBytes(h),
+                           h->resident_stream, p, static_cast<uint32_t>(h->image_bytes), h->phase1_range);
+    else
+        hipLaunchKernelGGL((okStepCoopKernel<kPolicyNone, true, true>), dim3(h->grid_blocks), dim3(h->block_threads), coopLdsBytes(h),
+                           h->resident_stream, p, static_cast<uint32_t>(h->image_bytes), h->phase1_range);
     OK_HIP(h, hipGetLastError());
     h->resident = true;
     return OKENV_OK;
@@ -548,8 +560,12 @@ int launchStep(okenv *h, const OkStepParams &p)
                                    h->phase1_range);
             else if (policy == kPolicyMlp)
                 hipLaunchKernelGGL(okStepCoopKernel<kPolicyMlp>, grid, block, lds, h->stream, p, off, h->phase1_range);
+            else if (p.rec_in != nullptr && directIntervals(h))
+                hipLaunchKernelGGL((okStepCoopKernel<kPolicyNone, true, false, true>), grid, block, lds, h->stream, p, off, h->phase1_range);
             else if (p.rec_in != nullptr)
                 hipLaunchKernelGGL((okStepCoopKernel<kPolicyNone, true>), grid, block, lds, h->stream, p, off, h->phase1_range);
+            else if (directIntervals(h))
+                hipLaunchKernelGGL((okStepCoopKernel<kPolicyNone, false, false, true>), grid, block, lds, h->stream, p, off, h->phase1_range);
             else
                 hipLaunchKernelGGL(okStepCoopKernel<kPolicyNone>, grid, block, lds, h->stream, p, off, h->phase1_range);
         }
@@ -690,6 +706,12 @@ extern "C"
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, true>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, true, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, false, false, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, true, false, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, true, true, true>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyMlp>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));

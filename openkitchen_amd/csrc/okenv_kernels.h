@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
 #endif
 constexpr int kMaxSplit = OKENV_MAX_SPLIT; // intervals a pending ray is cut into at most
 
-template <int kPolicy, bool kPacked = false, bool kResident = false>
+template <int kPolicy, bool kPacked = false, bool kResident = false, bool kDirect = false>
 __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, const uint32_t off_coop, const float phase1_range)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
@@ -726,11 +726,27 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
     const int  r        = static_cast<int>(gl % G); // blockDim.x is a multiple of G
     const bool agent_ok = agent < p.N && (p.agents_per_block <= 0 || in_block < p.agents_per_block);
     const int  a        = agent_ok ? agent : 0;
-    const bool ray_ok   = agent_ok && (r < p.R);
-    const long k        = static_cast<long>(a) * p.R + (ray_ok ? r : 0);
+    // Which ray a lane works on.  Normally lane r of the group has ray r.  A group with spare lanes and no phase 1 (policy-free
+    // kernels) is dealt out directly instead: ray q gets the `dm` consecutive lanes q * dm .. q * dm + dm - 1, lane j of them walks
+    // the j-th of dm intervals of the ray and the first of them (j == 0) does the ray's epilogue -- the same cut as phase 2 makes,
+    // without its ballot / permute / shuffles, because here it is the same for every step.
+    // (kDirect is a template parameter and not a launch-time test because the headline instantiation has no register to spare:
+    // the host picks it when phase1_range == 0, G >= 2 R and no policy is attached)
+    constexpr bool direct = kDirect;
+    int        dm = 1, ray = r, part = 0;
+    if (direct)
+    {
+        dm   = G / p.R;
+        dm   = dm > kMaxSplit ? kMaxSplit : dm;
+        ray  = r / dm;
+        part = r - ray * dm;
+    }
+    const bool ray_ok   = agent_ok && (ray < p.R);    // this lane walks (a part of) ray `ray`
+    const bool out_ok   = ray_ok && part == 0;       // ... and is the one that finishes it (hit point, transform, outputs)
+    const long k        = static_cast<long>(a) * p.R + (ray_ok ? ray : 0);
     // the agent's state is asked for before the image is staged, so that its round trip (to the host's memory over PCIe in the
     // packed exchange: 1.5 us) runs under the staging instead of after it
-    const float ray_deg = p.ray_deg[ray_ok ? r : 0];
+    const float ray_deg = p.ray_deg[ray_ok ? ray : 0];
     OkAgentRegs        ag{};
     okenv_agent_record rc_in{};
     if (!kResident)
@@ -919,7 +935,30 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
             // ---- phase 1: own ray over [0, T1] ----------------------------------------------------------
             bool  unfinished = false;
             float t_reached  = 0.F;
-            if (casts && phase1_range > 0.F)
+            if (direct)
+            { // the lane's own interval of its ray; the intervals tile [0, inf) whatever dt rounds to (last one open-ended)
+                float found = OK_SENSOR_RANGE;
+                if (casts)
+                {
+                    const float dt = OK_SENSOR_RANGE * okRcpApprox(static_cast<float>(dm));
+                    const float ta = static_cast<float>(part) * dt;
+                    const float tb = (part + 1 == dm) ? OKRC_INF : static_cast<float>(part + 1) * dt;
+                    found          = ok_cast_poly_interval<false>(view, ox, oy, rdx, rdy, ta, tb, nullptr, nullptr, nullptr OK_WPROF(5)).min_t;
+                }
+                if ((dm & (dm - 1)) == 0)
+                    found = okGroupMin(found, dm); // aligned groups of a power of two: DPP
+                else
+                {
+                    for (int off = 1; off < dm; off <<= 1)
+                    {
+                        const float other = __shfl_down(found, off, 64);
+                        if (part + off < dm && other < found)
+                            found = other;
+                    }
+                }
+                min_t = found; // (valid on the ray's first lane, which is the one that uses it)
+            }
+            else if (casts && phase1_range > 0.F)
             {
                 const OkIntervalResult r1 =
                     ok_cast_poly_interval<false>(view, ox, oy, rdx, rdy, 0.F, phase1_range, nullptr, nullptr, nullptr OK_WPROF(0));
@@ -928,7 +967,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
                 t_reached  = r1.t_reached;
             }
             else
-                unfinished = casts; // no phase 1 (far more lanes than rays): phase 2 cuts the whole ray into intervals
+                unfinished = casts; // no phase 1 (spare lanes, but a policy that wants ray r on lane r): phase 2 cuts the whole ray
             OK_STAMP(1);
             // ---- phase 2: the wave's unfinished rays, cut into m intervals each, over the wave's 64 lanes ------
             const unsigned long long pending = __ballot(unfinished);
@@ -995,7 +1034,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
 
             // ---- hit point, transform, crash test (CollisionChecker.cu:69-70,144-172) -----------------------------------
             float min_d2 = OK_SENSOR_RANGE * OK_SENSOR_RANGE;
-            if (ray_ok)
+            if (out_ok)
             {
                 float hx, hy;
                 if (casts)
@@ -1167,7 +1206,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
             okStoreAgent(p.st, a, ag);
         if (kPacked)
         {
-            if (ray_ok)
+            if (out_ok)
             {
                 p.hits_xy_out[2 * k]     = last_rel_x;
                 p.hits_xy_out[2 * k + 1] = last_rel_y;
