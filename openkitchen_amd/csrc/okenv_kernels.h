@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
 #endif
 constexpr int kMaxSplit = OKENV_MAX_SPLIT; // intervals a pending ray is cut into at most
 
-template <int kPolicy, bool kPacked = false, bool kResident = false, bool kDirect = false>
+template <int kPolicy, bool kPacked = false, bool kResident = false, bool kDirect = false, int kG = 0>
 __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, const uint32_t off_coop, const float phase1_range)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
@@ -718,7 +718,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, c
     if (threadIdx.x < 4)
         lds_progress[threadIdx.x] = 0U;
 
-    const int G = p.G;
+    const int G = kG > 0 ? kG : p.G; // (kG: the group width as a compile-time constant)
     // lane -> (agent, ray): densely over the grid, or -- tiny populations -- a few agents in the first lanes of every workgroup
     const long gl       = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
     const int  in_block = static_cast<int>(threadIdx.x) / G;
