@@ -88,23 +88,27 @@ def test_resident_starts_by_itself_and_yields_to_other_calls(gpu, oracle, monkey
     monkeypatch.delenv("OKENV_RESIDENT", raising=False)
     run = Run(gpu, oracle, *make(gpu, oracle, 15, 5, track="Silverstone", seed=3))
     dev = run.dev
-    run.steps(80)          # a tight loop: after 16 quick steps the kernel stays
-    assert dev.info()["packed_resident"] == 1 and dev.info()["packed_resident_steps"] > 20
+    run.steps(200)         # a tight loop: after 16 quick steps the kernel stays (a hiccup of the host may restart the count)
+    assert dev.info()["packed_resident_steps"] > 50
+    run.check()
+    run.steps(40)
+    assert dev.info()["packed_resident"] == 1
     run.check()
     # any other call stops it first and sees the state of the last step
     o = run.orc.snapshot()
     assert np.array_equal(dev.get(gpu.capi.F_POS_X).view(np.uint32), o["pos_x"].view(np.uint32))
     assert np.array_equal(np.asarray(dev.get(gpu.capi.F_HIT_X)).view(np.uint32).ravel(), o["hit_x"].view(np.uint32).ravel())
     assert dev.info()["packed_resident"] == 0
-    run.steps(60)          # ... and comes back
-    assert dev.info()["packed_resident"] == 1
+    before = dev.info()["packed_resident_steps"]
+    run.steps(100)         # ... and comes back
+    assert dev.info()["packed_resident"] == 1 and dev.info()["packed_resident_steps"] > before + 20
     served = dev.info()["packed_resident_steps"]
     time.sleep(0.005)      # longer than the kernel waits: it has left, the next step is a launch of its own
     run.steps(1)
     assert dev.info()["packed_resident"] == 0 and dev.info()["packed_resident_steps"] == served
     run.steps(5, pause=0.001)   # slow steps never make it resident
     assert dev.info()["packed_resident"] == 0 and dev.info()["packed_fallbacks"] == 0
-    assert run.check() == 66
+    assert run.check() == 106
     dev.close()
 
 
