@@ -558,6 +558,8 @@ int launchStep(okenv *h, const OkStepParams &p)
             if (p.action_source == kActionsQLearning)
                 hipLaunchKernelGGL(okStepCoopKernel<kPolicyQ>, grid, block, lds + qLdsBytes(h), h->stream, p, off,
                                    h->phase1_range);
+            else if (policy == kPolicyMlp && h->G == 32) // C3 / C4's 32-ray fan: group width a compile-time constant (+3 %)
+                hipLaunchKernelGGL((okStepCoopKernel<kPolicyMlp, false, false, false, 32>), grid, block, lds, h->stream, p, off, h->phase1_range);
             else if (policy == kPolicyMlp)
                 hipLaunchKernelGGL(okStepCoopKernel<kPolicyMlp>, grid, block, lds, h->stream, p, off, h->phase1_range);
             else if (p.rec_in != nullptr && directIntervals(h))
@@ -721,6 +723,8 @@ extern "C"
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyQ>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyMlp, false, false, false, 32>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okDebugCastKernel<kGridLds>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->image_bytes)));
         }
