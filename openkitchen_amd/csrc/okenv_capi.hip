@@ -101,7 +101,7 @@ struct okenv
     int         resident_served_now{0}; // steps the current residency has served
     int         packed_streak{0};   // packed steps in a row that came within kResidentGapUs of the one before
     std::chrono::steady_clock::time_point packed_last_end{};
-    size_t      stage_done_off{0}, stage_slots_off{0};
+    size_t      stage_slots_off{0}; // where the agents' slots lie in h_stage
     float       phase1_range{48.F}; // T1 of the cooperative kernel [px]
     std::string last_error;
     bool        timing{false};
@@ -417,7 +417,6 @@ bool directIntervals(const okenv *h)
 {
     return h->phase1_range <= 0.F && h->G >= 2 * h->R;
 }
-
 
 // Starts the resident kernel on a stream of its own; `p` carries the exchange pointers of okenv_step_packed.
 int startResident(okenv *h, OkStepParams p, volatile uint32_t *slots)
@@ -1264,7 +1263,6 @@ extern "C"
             h->h_stage         = pinned;
             h->h_stage_device  = mapped;
             h->d_stage         = d;
-            h->stage_done_off  = done_off;
             h->stage_slots_off = slots_off;
         }
         uint8_t *hs = static_cast<uint8_t *>(h->h_stage), *ds = static_cast<uint8_t *>(h->d_stage);
