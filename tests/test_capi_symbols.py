@@ -59,3 +59,24 @@ def test_product_has_no_oracle_dependency():
                 if f.endswith((".py", ".h", ".hip", ".cpp", ".c")):
                     text = open(os.path.join(dirpath, f), errors="ignore").read()
                     assert "_oracle" not in text and "oracle/" not in text.replace("under oracle/", ""), os.path.join(dirpath, f)
+
+
+def test_every_handle_entry_point_stops_a_resident_kernel_first():
+    """While a resident step kernel serves okenv_step_packed nothing else may run against the handle's state: every C-ABI
+    function that takes the handle begins with OK_QUIESCE(h).  The exceptions are listed: okenv_step_packed (it IS the
+    resident path), okenv_destroy (stops it itself), okenv_get_info / okenv_last_error (host-side data only) and
+    okenv_set_sensor_offset (quiesces only when the value changes: the facade calls it before every step)."""
+    src = open(os.path.join(ROOT, "openkitchen_amd", "csrc", "okenv_capi.hip")).read()
+    exempt = {"okenv_step_packed", "okenv_destroy", "okenv_get_info", "okenv_last_error", "okenv_set_sensor_offset"}
+    seen = 0
+    for m in re.finditer(r"^    (?:__attribute__\(\(visibility\(\"default\"\)\)\) )?(?:int|const char \*)\s*(okenv_\w+)\(okenv_t h\b[^{]*\{\n(.*?)\n", src, re.M | re.S):
+        name, first_line = m.group(1), m.group(2)
+        seen += 1
+        if name in exempt:
+            continue
+        assert "OK_QUIESCE(h);" in first_line, name
+    assert seen >= 45
+    body = src[src.index("int okenv_set_sensor_offset(okenv_t h"):]
+    assert "OK_QUIESCE(h);" in body[:600]
+    body = src[src.index("int okenv_destroy(okenv_t h"):]
+    assert "stopResident(h)" in body[:600]
