@@ -567,6 +567,9 @@ int launchStep(okenv *h, const OkStepParams &p)
                 hipLaunchKernelGGL((okStepCoopKernel<kPolicyNone, true>), grid, block, lds, h->stream, p, off, h->phase1_range);
             else if (directIntervals(h))
                 hipLaunchKernelGGL((okStepCoopKernel<kPolicyNone, false, false, true>), grid, block, lds, h->stream, p, off, h->phase1_range);
+            else if (h->G == 64 && p.action_source == kActionsPhiloxReset && p.do_move != 0 && p.reset_flags == 0U)
+                // okenv_rollout_random without device-side resetAgent: its launch-time switches as constants (-1 %)
+                hipLaunchKernelGGL((okStepCoopKernel<kPolicyNone, false, false, false, 64, true>), grid, block, lds, h->stream, p, off, h->phase1_range);
             else if (h->G == 64) // one agent per wave, the group width a compile-time constant (-1 % on 20-step launches)
                 hipLaunchKernelGGL((okStepCoopKernel<kPolicyNone, false, false, false, 64>), grid, block, lds, h->stream, p, off, h->phase1_range);
             else
@@ -709,6 +712,8 @@ extern "C"
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, true>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, true, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, false, false, false, 64, true>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, false, false, false, 64>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));

@@ -689,9 +689,18 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
 #endif
 constexpr int kMaxSplit = OKENV_MAX_SPLIT; // intervals a pending ray is cut into at most
 
-template <int kPolicy, bool kPacked = false, bool kResident = false, bool kDirect = false, int kG = 0>
-__global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p, const uint32_t off_coop, const float phase1_range)
+template <int kPolicy, bool kPacked = false, bool kResident = false, bool kDirect = false, int kG = 0, bool kDriver = false>
+__global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in, const uint32_t off_coop, const float phase1_range)
 {
+    // kDriver: the bench driver's launch (Philox actions + reset of crashed agents, kinematics on, no device-side resetAgent): the
+    // three launch-time switches become constants
+    OkStepParams p = p_in;
+    if (kDriver)
+    {
+        p.action_source = kActionsPhiloxReset;
+        p.do_move       = 1;
+        p.reset_flags   = 0U;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
     // Q-learning scans the centre line every step (reward = progress along it): keep it in LDS, behind the image
     // LDS behind the image: four progress words (one per SIMD, see OKENV_PRIO below), then the Q-learning data
