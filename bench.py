@@ -129,18 +129,28 @@ def bench_callers(args, torch, local_rank, log):
     out["vector_env_torch_policy_graph"] = {"value": N * steps / dt, "unit": "agent-steps/s", "us_per_step": dt / steps * 1e6,
                                             "workload": "same iteration, captured into one HIP graph and replayed"}
     venv.close()
-    racers = CmaEsRacers(args.track, N, device=local_rank, seed=args.seed, max_steps=400)
-    racers.run_generation()  # warm-up (eigh, allocator)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    best, gsteps = racers.run_generation()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    out["cmaes_generation"] = {
-        "value": N * gsteps / dt, "unit": "agent-steps/s", "generation_ms": dt * 1e3, "steps": gsteps, "best_fitness": best,
-        "workload": "population %d (reference: 20), 250 parameters, controller 5-16-8-2 in PyTorch, iteration replayed as one HIP "
-                    "graph, index-progress fitness on the device; includes sampling and the host eigendecomposition" % N}
-    racers.venv.close()
+    for key, fused in (("cmaes_generation", True), ("cmaes_generation_torch_controller", False)):
+        racers = CmaEsRacers(args.track, N, device=local_rank, seed=args.seed, max_steps=400, fused=fused)
+        racers.run_generation()  # warm-up (eigh, allocator, graph capture)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        best, gsteps = racers.run_generation()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # the loop alone: the same generation's iteration graph replayed gsteps times, without sampling / eigh / tell
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(gsteps):
+            racers._graph.replay()
+        torch.cuda.synchronize()
+        loop_dt = time.perf_counter() - t1
+        out[key] = {
+            "value": N * gsteps / dt, "unit": "agent-steps/s", "generation_ms": dt * 1e3, "steps": gsteps, "best_fitness": best,
+            "loop_us_per_step": loop_dt / gsteps * 1e6,
+            "workload": "population %d (reference: 20), 250 parameters, controller 5-16-8-2 %s, iteration (controller, Environment::step, "
+                        "index-progress fitness) replayed as one HIP graph; generation_ms includes sampling and the host "
+                        "eigendecomposition of the 250 x 250 covariance" % (N, "as a libokenv kernel (okenv_controller_act)" if fused else "in PyTorch")}
+        racers.venv.close()
     # the C++ drop-in classes (include/Environment/): microseconds per Environment::step() at the population sizes the
     # reference's applications use (Template 1, PPO / REINFORCE 15, EvolutionaryRacer 50 agents); five-ray fan
     try:

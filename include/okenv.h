@@ -202,6 +202,19 @@ OKENV_API int okenv_tracker_begin(okenv_t h);
  * initial observation).  An agent that crashes in this step gets OKENV_F_EPISODE_RETURN := fitness. */
 OKENV_API int okenv_tracker_update(okenv_t h);
 
+/* The CMA-ES candidates' controllers on the device (CovarianceMatrixAdaptationEvolution/Controller.cpp:3-23: fc1 rays ->
+ * hidden, fc2 hidden -> hidden / 2, fc3 hidden / 2 -> 2, tanh after each; main_eigen.cpp:18-19 uses hidden = 16), one
+ * parameter vector per agent in the order of torch's parameters() (Controller.cpp:36-53).  hidden: even, 2..64. */
+OKENV_API int okenv_controller_create(okenv_t h, int32_t hidden);
+OKENV_API int okenv_controller_num_params(okenv_t h, int32_t *out);
+/* Controller::set_params for every agent: params[num_agents][num_params], host or device pointer (e.g. the solver's
+ * sample tensor). */
+OKENV_API int okenv_controller_set_params(okenv_t h, const float *params);
+/* CmaEsAgent::updateAction for every agent (main_eigen.cpp:58-68): input ||sensor_hits_[i]|| / kSensorRange of the last
+ * step, throttle_delta = throttle, steering_delta = output[0] * steering_scale (100 and 5 in the reference).  One kernel on
+ * the handle's stream, no synchronisation: it can be captured into a HIP graph next to okenv_step. */
+OKENV_API int okenv_controller_act(okenv_t h, float throttle, float steering_scale);
+
 /* ---- zero-copy access for device-side callers ------------------------ */
 
 /* Device address and size of one library-owned struct-of-arrays field (okenv_field), valid for the handle's lifetime.

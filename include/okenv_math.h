@@ -233,6 +233,57 @@ OK_HD float ok_normalize_angle_deg(float angle)
     return angle;
 }
 
+/* tanh for the CMA-ES controller (CovarianceMatrixAdaptationEvolution/Controller.cpp:16-23), evaluated in fp64 with basic
+ * IEEE operations only (no FMA contraction, no library call), so that the device and the CPU oracle produce the same bits
+ * -- the same idea as ok_sincosf.  tanh|x| = (1 - e) / (1 + e), e = exp(-2|x|) = 2^n * exp(r), n = rint(-2|x| / ln 2),
+ * |r| <= ln2 / 2, exp(r) by its Taylor series to r^13 (truncation < 5e-18); the fp64 result is off by a few 1e-16 relative
+ * except for the cancellation in 1 - e at small |x| (2^-53 / 2|x|: 2^-42 at the 2^-12 below which tanh x rounds to x), i.e.
+ * the float result is the correctly rounded one but for rare near-ties (tests/test_math.py: equal to the rounded fp64 tanh
+ * on a million samples; glibc's tanhf, not correctly rounded itself, is within 2 ulps of it). */
+OK_HD float ok_tanhf(const float x)
+{
+    const double ax = __builtin_fabs((double)x);
+    if (!(ax >= 0.000244140625)) /* |x| < 2^-12: x^3/3 is below half an ulp of x; NaN takes this exit too and stays NaN */
+        return x;
+    const double y  = -2.0 * (ax < 20.0 ? ax : 20.0); /* tanh(20) is 1 to 17 digits: larger arguments change nothing */
+    const double n  = OK_RINT(y * 1.44269504088896338700);
+    const double L1 = 6.93147180369123816490e-01; /* ln 2 in two parts, the first with 32 significant bits: n * L1 is exact */
+    const double L2 = 1.90821492927058770002e-10;
+    double r = y - n * L1;
+    r = r - n * L2;
+    double p = 1.605904383682161459939237717015494793273e-10; /* 1/13! */
+    p = p * r + 2.087675698786809897921009032120143231254e-09;  /* 1/12! */
+    p = p * r + 2.505210838544171877505210838544171877505e-08;  /* 1/11! */
+    p = p * r + 2.755731922398589065255731922398589065256e-07;  /* 1/10! */
+    p = p * r + 2.755731922398589065255731922398589065256e-06;  /* 1/9!  */
+    p = p * r + 2.480158730158730158730158730158730158730e-05;  /* 1/8!  */
+    p = p * r + 1.984126984126984126984126984126984126984e-04;  /* 1/7!  */
+    p = p * r + 1.388888888888888888888888888888888888889e-03;  /* 1/6!  */
+    p = p * r + 8.333333333333333333333333333333333333333e-03;  /* 1/5!  */
+    p = p * r + 4.166666666666666666666666666666666666667e-02;  /* 1/4!  */
+    p = p * r + 1.666666666666666666666666666666666666667e-01;  /* 1/3!  */
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    union { uint64_t u; double d; } two_n; /* 2^n, n in [-58, 0] */
+    two_n.u = (uint64_t)(1023 + (int)n) << 52;
+    const double e = p * two_n.d;
+    const double t = (1.0 - e) / (1.0 + e);
+    return (float)(x < 0.0f ? -t : t);
+}
+
+/* One candidate's controller (Controller.cpp:3-23: fc1 in->h, fc2 h->h/2, fc3 h/2->out, tanh after each) on the input
+ * CmaEsAgent::stateToTensor builds (main_eigen.cpp:45-56: ||sensor_hits_[i]|| / kSensorRange).  `params` in the order of
+ * torch's parameters(): fc1.weight [h][in] row-major, fc1.bias [h], fc2.weight [h/2][h], fc2.bias, fc3.weight [out][h/2],
+ * fc3.bias (Controller.cpp:36-53).  A unit's sum starts from its bias and adds w * x in ascending input order, fp32, no
+ * FMA (libtorch's own order inside addmm is not specified): okControllerKernel on the device, ctrl_forward in the oracle.
+ * h <= 64. */
+#define OK_CTRL_MAX_HIDDEN 64
+OK_HD int ok_controller_num_params(const int in, const int hidden, const int out)
+{
+    const int h2 = hidden / 2;
+    return hidden * in + hidden + h2 * hidden + h2 + out * h2 + out;
+}
 /* nn_output > kOutputActivationLim (GeneticAgent.hpp:45-54) on a PRE-activation z, where nn_output = sigmoid(z) =
  * 1.F / (1.F + exp(-z)) in fp32 (Network.hpp:162-165).  The quotient exceeds 0.5 exactly when the rounded sum 1 + exp(-z)
  * is below 2, i.e. when exp(-z) rounds to 1 - 2^-23 or less, i.e. when exp(-z) <= 1 - 1.5 * 2^-24 (the tie goes to the even

@@ -45,6 +45,7 @@ SYMBOLS = [
     "okenv_set_lane_bounds", "okenv_reset_random", "okenv_set_auto_reset", "okenv_get_step_count",
     "okenv_set_step_count", "okenv_field_device_ptr", "okenv_tracker_create", "okenv_tracker_begin",
     "okenv_tracker_update", "okenv_step_packed",
+    "okenv_controller_create", "okenv_controller_num_params", "okenv_controller_set_params", "okenv_controller_act",
 ]
 
 
@@ -148,6 +149,10 @@ def load(build_if_missing=True):
     L.okenv_get_step_count.argtypes = [vp, C.POINTER(u32)]
     L.okenv_set_step_count.argtypes = [vp, u32]
     L.okenv_step_packed.argtypes = [vp, vp, vp, vp, u32]
+    L.okenv_controller_create.argtypes = [vp, C.c_int32]
+    L.okenv_controller_num_params.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.okenv_controller_set_params.argtypes = [vp, vp]
+    L.okenv_controller_act.argtypes = [vp, C.c_float, C.c_float]
     L.okenv_tracker_create.argtypes = [vp, i32]
     L.okenv_tracker_begin.argtypes = [vp]
     L.okenv_tracker_update.argtypes = [vp]

@@ -5,8 +5,9 @@ Mirror of the reference's CovarianceMatrixAdaptationEvolution app for N candidat
   * `BatchedController`-- Controller.cpp:3-23, one parameter vector per candidate, evaluated for all candidates at once
   * `CmaEsRacers`      -- the generation loop of main_eigen.cpp:113-171: sample, resetAgent, one observation step, then
                           {updateAction; env.step(); fitness += |index progress|} until every candidate has crashed.
-The environment step and the fitness bookkeeping are libokenv.so kernels (okenv_step, okenv_tracker_update); the
-policy forward is plain PyTorch on the same stream.  The reference seeds std::mt19937 from std::random_device
+The environment step, the candidates' controllers and the fitness bookkeeping are libokenv.so kernels (okenv_step,
+okenv_controller_act, okenv_tracker_update): three launches per iteration, replayed as one HIP graph.  `fused=False`
+evaluates the controllers in plain PyTorch instead (`BatchedController`, a dozen small kernels per iteration).  The reference seeds std::mt19937 from std::random_device
 (CmaEsSolverEigen.h:49), so its sample streams are not reproducible; here a seeded numpy Generator draws z.
 """
 import numpy as np
@@ -127,18 +128,33 @@ class CmaEsRacers:
     RAYS = (-70.0, -30.0, 0.0, 30.0, 70.0)  # CmaEsAgent's fan (main_eigen.cpp:26-31)
     HIDDEN, OUTPUTS = 16, 2                  # main_eigen.cpp:18-19
 
-    def __init__(self, track, population_size=20, device=0, seed=0, reset_randomly=False, max_steps=None):
+    def __init__(self, track, population_size=20, device=0, seed=0, reset_randomly=False, max_steps=None, fused=True):
         self.venv = VectorEnvironment(track, population_size, ray_angles_deg=np.array(self.RAYS, dtype=np.float32),
                                       device=device, movement_mode=capi.MODE_VELOCITY, auto_reset=False,
                                       pick_random_point=reset_randomly, seed=seed, reward="progress")
+        self.fused = bool(fused)
         self.controller = BatchedController(len(self.RAYS), self.HIDDEN, self.OUTPUTS, self.venv.device, population_size)
+        if self.fused:
+            assert self.venv.env.controller_create(self.HIDDEN) == self.controller.count_params()
         self.solver = CmaEsSolver(self.controller.count_params(), population_size, seed=seed, device=self.venv.device)
         self.max_steps = max_steps
         self.generation = 0
         self._graph = None
 
+    def set_params(self, population):
+        """Controller::set_params for every candidate (main_eigen.cpp:120-125)."""
+        if self.fused:
+            if torch.is_tensor(population):
+                population = population.to(device=self.venv.device, dtype=torch.float32).contiguous()
+            self.venv.env.controller_set_params(population)
+        else:
+            self.controller.set_params(population)
+
     def update_action(self):
         """CmaEsAgent::updateAction (main_eigen.cpp:58-68): full throttle, steering = 5 * first output."""
+        if self.fused:
+            self.venv.env.controller_act(100.0, 5.0)
+            return
         out = self.controller.forward(self.venv.observation())
         self.venv.set_action(100.0, out[:, 0] * 5.0)
 
@@ -152,7 +168,7 @@ class CmaEsRacers:
         HIP graph and replayed; `use_graph=False` launches it eagerly."""
         venv = self.venv
         population = self.solver.sample()
-        self.controller.set_params(population)
+        self.set_params(population)
         if use_graph and self._graph is None:
             self._graph = venv.capture(self._iteration, warmup=2)
         # resetAgent for every candidate, the initial-observation step, prev_track_idx_ (main_eigen.cpp:120-133)

@@ -78,6 +78,8 @@ struct okenv
     int32_t *d_q_state{nullptr}, *d_q_action{nullptr}, *d_q_prev{nullptr}, *d_q_reset_nearest{nullptr};
     void    *d_scratch{nullptr};       // staging for calls that take host arrays (every user synchronises before it returns)
     size_t   scratch_bytes{0};
+    float   *d_ctrl_params{nullptr};   // CMA-ES controllers: [N][ctrl_num_params]
+    int      ctrl_hidden{0}, ctrl_num_params{0};
     float   *d_q_reset_query{nullptr}; // (x, y) of the episode's reset point, the query of its nearest-index kernel
     float    q_reset_query[2]{0.F, 0.F}; // host copy the upload reads: lives as long as the handle
     float   *d_q_sums{nullptr};
@@ -1517,6 +1519,67 @@ extern "C"
     {
         OK_QUIESCE(h);
         return launchTracker(h, 0, "okenv_tracker_update");
+    }
+
+    // ---- CMA-ES controller -----------------------------------------------------------------------------------------
+
+    int okenv_controller_create(okenv_t h, int32_t hidden)
+    {
+        OK_QUIESCE(h);
+        if (!h || hidden < 2 || hidden > OK_CTRL_MAX_HIDDEN || (hidden & 1) != 0)
+            return fail(h, OKENV_ERR_INVALID, "okenv_controller_create: hidden width must be even and in [2, 64]");
+        if (h->R > 64)
+            return fail(h, OKENV_ERR_INVALID, "okenv_controller_create: at most 64 rays");
+        OK_HIP(h, hipSetDevice(h->device));
+        const int np = ok_controller_num_params(h->R, hidden, 2);
+        if (!h->d_ctrl_params || np != h->ctrl_num_params)
+        {
+            const int rc = devAlloc(h, &h->d_ctrl_params, static_cast<size_t>(h->N) * np);
+            if (rc != OKENV_OK)
+                return rc;
+        }
+        h->ctrl_hidden     = hidden;
+        h->ctrl_num_params = np;
+        return OKENV_OK;
+    }
+
+    int okenv_controller_num_params(okenv_t h, int32_t *out)
+    {
+        OK_QUIESCE(h);
+        if (!h || !out || !h->d_ctrl_params)
+            return fail(h, OKENV_ERR_STATE, "okenv_controller_num_params: call okenv_controller_create first");
+        *out = h->ctrl_num_params;
+        return OKENV_OK;
+    }
+
+    int okenv_controller_set_params(okenv_t h, const float *params)
+    {
+        OK_QUIESCE(h);
+        if (!h || !params || !h->d_ctrl_params)
+            return fail(h, OKENV_ERR_STATE, "okenv_controller_set_params: call okenv_controller_create first");
+        OK_HIP(h, hipSetDevice(h->device));
+        return copyAny(h, h->d_ctrl_params, params, sizeof(float) * static_cast<size_t>(h->N) * h->ctrl_num_params);
+    }
+
+    int okenv_controller_act(okenv_t h, float throttle, float steering_scale)
+    {
+        OK_QUIESCE(h);
+        if (!h || !h->d_ctrl_params)
+            return fail(h, OKENV_ERR_STATE, "okenv_controller_act: call okenv_controller_create first");
+        OK_HIP(h, hipSetDevice(h->device));
+        const int      lanes  = h->ctrl_hidden <= 16 ? 16 : (h->ctrl_hidden <= 32 ? 32 : 64);
+        const unsigned blocks = static_cast<unsigned>((static_cast<long>(h->N) * lanes + 255) / 256);
+        if (lanes == 16)
+            hipLaunchKernelGGL(okControllerKernel<16>, dim3(blocks), dim3(256), 0, h->stream, h->st, h->d_ctrl_params, h->ctrl_num_params, h->N,
+                               h->R, h->ctrl_hidden, throttle, steering_scale);
+        else if (lanes == 32)
+            hipLaunchKernelGGL(okControllerKernel<32>, dim3(blocks), dim3(256), 0, h->stream, h->st, h->d_ctrl_params, h->ctrl_num_params, h->N,
+                               h->R, h->ctrl_hidden, throttle, steering_scale);
+        else
+            hipLaunchKernelGGL(okControllerKernel<64>, dim3(blocks), dim3(256), 0, h->stream, h->st, h->d_ctrl_params, h->ctrl_num_params, h->N,
+                               h->R, h->ctrl_hidden, throttle, steering_scale);
+        OK_HIP(h, hipGetLastError());
+        return OKENV_OK;
     }
 
     // ---- EvolutionaryRacer ---------------------------------------------------------------------------------------

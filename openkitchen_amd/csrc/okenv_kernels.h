@@ -1484,6 +1484,56 @@ __global__ void okNearestIdxKernel(const float *cx, const float *cy, int P, cons
         out[i] = arg;
 }
 
+// ---- CMA-ES controller ---------------------------------------------------------------
+// CmaEsAgent::updateAction for the whole population (CovarianceMatrixAdaptationEvolution/main_eigen.cpp:45-68, Controller.cpp:
+// 3-23): kLanes lanes per candidate, lane j evaluates unit j of a layer (its row of the weight matrix against the previous
+// layer's outputs, fetched from the other lanes by shuffles), three layers = three rounds.  Sums start from the bias and add
+// w * x in ascending input order (fp32, no FMA), as the oracle's ctrl_forward does.  One launch per Environment step, on the
+// handle's stream: captured into the caller's HIP graph together with okenv_step and the tracker.
+template <int kLanes>
+__global__ void okControllerKernel(OkDeviceState st, const float *params, int num_params, int N, int R, int hidden, float throttle, float steering_scale)
+{
+    const int  gid  = blockIdx.x * blockDim.x + threadIdx.x;
+    const int  a    = gid / kLanes;
+    const int  j    = gid % kLanes;
+    const bool ok   = a < N;
+    const int  ac   = ok ? a : 0;
+    const int  h2   = hidden / 2;
+    const float *prm = params + static_cast<size_t>(ac) * num_params;
+    const float *w1 = prm, *b1 = w1 + hidden * R, *w2 = b1 + hidden, *b2 = w2 + h2 * hidden, *w3 = b2 + h2, *b3 = w3 + 2 * h2;
+    // layer 1: inputs are the agent's R distances / kSensorRange (every lane reads them; they sit in one or two cache lines)
+    float a1 = 0.F;
+    if (j < hidden)
+    {
+        float sum = b1[j];
+        for (int i = 0; i < R; ++i)
+            sum = sum + w1[j * R + i] * (st.dist[static_cast<long>(ac) * R + i] / OK_SENSOR_RANGE);
+        a1 = ok_tanhf(sum);
+    }
+    // layer 2: lane j < hidden / 2
+    float sum2 = (j < h2) ? b2[j] : 0.F;
+    for (int i = 0; i < hidden; ++i)
+    {
+        const float xi = __shfl(a1, i, kLanes);
+        if (j < h2)
+            sum2 = sum2 + w2[j * hidden + i] * xi;
+    }
+    const float a2 = (j < h2) ? ok_tanhf(sum2) : 0.F;
+    // layer 3: lanes 0 and 1 (only output 0 is used: steering; the throttle is a constant, main_eigen.cpp:65-67)
+    float sum3 = (j < 2) ? b3[j] : 0.F;
+    for (int i = 0; i < h2; ++i)
+    {
+        const float xi = __shfl(a2, i, kLanes);
+        if (j < 2)
+            sum3 = sum3 + w3[j * h2 + i] * xi;
+    }
+    if (ok && j == 0)
+    {
+        st.thr[a]   = throttle;
+        st.steer[a] = ok_tanhf(sum3) * steering_scale;
+    }
+}
+
 // ---- rollout bookkeeping ------------------------------------------------------------
 
 struct OkTracker

@@ -205,6 +205,24 @@ class BatchedEnvironment:
     def tracker_update(self):
         capi.check(self._L.okenv_tracker_update(self._h), self._h)
 
+    # ---- CMA-ES controllers ---------------------------------------------
+    def controller_create(self, hidden=16):
+        """Controller.cpp:3-23 for every agent: rays -> hidden -> hidden / 2 -> 2, tanh; returns the parameter count."""
+        capi.check(self._L.okenv_controller_create(self._h, int(hidden)), self._h)
+        n = C.c_int32()
+        capi.check(self._L.okenv_controller_num_params(self._h, C.byref(n)), self._h)
+        return int(n.value)
+
+    def controller_set_params(self, params):
+        """params [N, num_params]: numpy float32 array or a torch device tensor (torch parameters() order)."""
+        if isinstance(params, np.ndarray) or not hasattr(params, "data_ptr"):
+            params = np.ascontiguousarray(params, dtype=np.float32)
+        capi.check(self._L.okenv_controller_set_params(self._h, capi.ptr(params)), self._h)
+
+    def controller_act(self, throttle=100.0, steering_scale=5.0):
+        """CmaEsAgent::updateAction for every agent (main_eigen.cpp:58-68)."""
+        capi.check(self._L.okenv_controller_act(self._h, float(throttle), float(steering_scale)), self._h)
+
     def tracker_snapshot(self):
         return {capi.FIELD_NAMES[f]: self.get(f) for f in range(capi.F_REWARD, capi.F_EPISODE_RETURN + 1)}
 

@@ -59,6 +59,11 @@ ORACLE_API void oracle_sincosf(const float *x, float *s, float *c, int n)
     for (int i = 0; i < n; ++i) ok_sincosf(x[i], &s[i], &c[i]);
 }
 
+ORACLE_API void oracle_tanhf(const float *x, float *t, int n)
+{
+    for (int i = 0; i < n; ++i) t[i] = ok_tanhf(x[i]);
+}
+
 ORACLE_API void oracle_philox(uint32_t seed, uint32_t agent, uint32_t step, float *thr, float *steer, uint32_t *word)
 {
     ok_random_action a = ok_draw_random_action(seed, agent, step);
@@ -944,6 +949,47 @@ ORACLE_API void oracle_env_rollout_policy(oracle_env *e, int n_steps)
         step_all(e);
         e->step_count++;
     }
+}
+
+/* CmaEsAgent::updateAction for every agent (CovarianceMatrixAdaptationEvolution/main_eigen.cpp:45-68): the input is
+ * sensor_hits_[i].norm() / kSensorRange (:47-50), the controller tanh(fc3(tanh(fc2(tanh(fc1(x)))))) (Controller.cpp:16-23)
+ * with fc1: R -> hidden, fc2: hidden -> hidden / 2, fc3: hidden / 2 -> 2 (:3-8, main_eigen.cpp:18-19); throttle_delta is a
+ * constant and steering_delta = output[0] * scale (:65-67; 100 and 5 in the reference).  `params`: N rows in the order of
+ * torch's parameters().  Sums run from the bias on, inputs ascending (see include/okenv_math.h on why that is a choice). */
+static void ctrl_forward(const float *prm, const float *x, int in, int hidden, float *out2)
+{
+    const int h2 = hidden / 2;
+    float a1[OK_CTRL_MAX_HIDDEN], a2[OK_CTRL_MAX_HIDDEN];
+    const float *w1 = prm, *b1 = w1 + hidden * in, *w2 = b1 + hidden, *b2 = w2 + h2 * hidden, *w3 = b2 + h2, *b3 = w3 + 2 * h2;
+    for (int j = 0; j < hidden; ++j) {
+        float sum = b1[j];
+        for (int i = 0; i < in; ++i) sum = sum + w1[j * in + i] * x[i];
+        a1[j] = ok_tanhf(sum);
+    }
+    for (int j = 0; j < h2; ++j) {
+        float sum = b2[j];
+        for (int i = 0; i < hidden; ++i) sum = sum + w2[j * hidden + i] * a1[i];
+        a2[j] = ok_tanhf(sum);
+    }
+    for (int j = 0; j < 2; ++j) {
+        float sum = b3[j];
+        for (int i = 0; i < h2; ++i) sum = sum + w3[j * h2 + i] * a2[i];
+        out2[j] = ok_tanhf(sum);
+    }
+}
+
+ORACLE_API int oracle_env_controller_act(oracle_env *e, const float *params, int hidden, float throttle, float steering_scale)
+{
+    if (hidden < 2 || hidden > OK_CTRL_MAX_HIDDEN || (hidden & 1) || e->R > 64) return -1;
+    const int np = hidden * e->R + hidden + (hidden / 2) * hidden + hidden / 2 + 2 * (hidden / 2) + 2;
+    for (int a = 0; a < e->N; ++a) {
+        float x[64], out2[2];
+        for (int i = 0; i < e->R; ++i) x[i] = e->dist[(size_t)a * e->R + i] / 200.0f;
+        ctrl_forward(params + (size_t)a * np, x, e->R, hidden, out2);
+        e->thr[a]   = throttle;
+        e->steer[a] = out2[0] * steering_scale;
+    }
+    return 0;
 }
 
 ORACLE_API int oracle_env_alive_count(const oracle_env *e)

@@ -89,6 +89,9 @@ def lib():
         L.oracle_env_init_bench_state.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
         L.oracle_sincosf.argtypes = [f32p, f32p, f32p, C.c_int]
         L.oracle_ga_decode.argtypes = [f32p, C.c_int, f32p, f32p, f32p, f32p]
+        L.oracle_tanhf.argtypes = [f32p, f32p, C.c_int]
+        L.oracle_env_controller_act.argtypes = [C.c_void_p, f32p, C.c_int, C.c_float, C.c_float]
+        L.oracle_env_controller_act.restype = C.c_int
         L.oracle_set_trig_mode.argtypes = [C.c_int]
         L.oracle_cast_ray.restype = C.c_float
         L.oracle_cast_ray.argtypes = [C.c_float, C.c_float, C.c_float, f32p, C.c_int]

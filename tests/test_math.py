@@ -99,3 +99,30 @@ def test_ga_output_threshold_equals_the_written_out_sigmoid(oracle):
     to, so, tp, sp = (np.zeros(3, dtype=np.float32) for _ in range(4))
     O.lib().oracle_ga_decode(probe, 3, to, so, tp, sp)
     assert so.tolist() == [0.0, 4.0, 4.0] and sp.tolist() == [0.0, 4.0, 4.0]
+
+
+def test_tanh_against_fp64_and_glibc(oracle):
+    """ok_tanhf (include/okenv_math.h, the CMA-ES controller's activation): <= 1 ulp from the correctly rounded value (and
+    equal to it on all but a handful of a million samples), within 2 ulps of glibc's tanhf (which is not correctly rounded
+    itself); odd; saturates; NaN stays NaN."""
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-12, 12, 400000), rng.normal(0, 1, 400000), rng.uniform(-1e-3, 1e-3, 100000),
+                        10.0 ** rng.uniform(-8, 1.5, 100000), np.linspace(-0.001, 0.001, 20001)]).astype(np.float32)
+    t = np.zeros_like(x)
+    O.lib().oracle_tanhf(x, t, x.size)
+    ref = np.tanh(x.astype(np.float64)).astype(np.float32)
+    d = ulp_diff(t, ref)
+    assert d.max() <= 1 and (d != 0).mean() < 1e-4
+    libm = C.CDLL("libm.so.6")
+    libm.tanhf.restype, libm.tanhf.argtypes = C.c_float, [C.c_float]
+    sub = x[::50]
+    g = np.array([libm.tanhf(float(v)) for v in sub], dtype=np.float32)
+    assert ulp_diff(t[::50], g).max() <= 2
+    tm = np.zeros_like(x)
+    O.lib().oracle_tanhf(-x, tm, x.size)
+    assert np.array_equal(tm.view(np.uint32), (-t).view(np.uint32))
+    sp = np.array([0.0, -0.0, 1e-30, 2.0 ** -12, 9.0, 10.0, 25.0, 1e30, np.inf, -np.inf, np.nan], dtype=np.float32)
+    ts = np.zeros_like(sp)
+    O.lib().oracle_tanhf(sp, ts, sp.size)
+    assert ts[0] == 0 and np.signbit(ts[1]) and ts[2] == sp[2] and ts[5] == 1 and ts[6] == 1 and ts[7] == 1 and ts[8] == 1 and ts[9] == -1
+    assert np.isnan(ts[10]) and abs(ts[4] - np.tanh(9.0)) < 1e-7
