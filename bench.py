@@ -137,7 +137,8 @@ def bench_callers(args, torch, local_rank, log):
         best, gsteps = racers.run_generation()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        # the loop alone: the same generation's iteration graph replayed gsteps times, without sampling / eigh / tell
+        # the loop alone: the iteration graph replayed gsteps times on a freshly reset population, without sampling / eigh / tell
+        racers.venv.reset(epoch=racers.generation)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(gsteps):
