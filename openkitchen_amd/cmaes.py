@@ -10,11 +10,24 @@ okenv_controller_act, okenv_tracker_update): three launches per iteration, repla
 evaluates the controllers in plain PyTorch instead (`BatchedController`, a dozen small kernels per iteration).  The reference seeds std::mt19937 from std::random_device
 (CmaEsSolverEigen.h:49), so its sample streams are not reproducible; here a seeded numpy Generator draws z.
 """
+import contextlib
+
 import numpy as np
 import torch
 
 from . import _capi as capi
 from .torch_env import VectorEnvironment
+
+try:  # the solver's 250 x 250 linear algebra gains nothing from dozens of BLAS threads, and their spin-waiting after each call
+    # can use up a container's CPU quota: the whole process is then paused until the next scheduler period (measured on the GPU
+    # box: a 21 ms generation took 100 ms)
+    from threadpoolctl import threadpool_limits as _threadpool_limits
+except ImportError:  # pragma: no cover
+    _threadpool_limits = None
+
+
+def _few_blas_threads():
+    return _threadpool_limits(limits=4) if _threadpool_limits is not None else contextlib.nullcontext()
 
 
 class CmaEsSolver:
@@ -47,7 +60,8 @@ class CmaEsSolver:
 
     def sample(self):
         """Candidates x_i = mean + sigma * B (D * z_i), z_i ~ N(0, I); returns float32 [population, num_params]."""
-        evals, self.B = np.linalg.eigh(self.C)
+        with _few_blas_threads():
+            evals, self.B = np.linalg.eigh(self.C)
         self.D = np.sqrt(evals)
         if self.device is None:
             z = self.rng.standard_normal((self.population_size, self.num_params))
@@ -67,6 +81,10 @@ class CmaEsSolver:
             parents = solutions[torch.as_tensor(order, device=solutions.device)].to(torch.float64).cpu().numpy()
         else:
             parents = np.asarray(solutions, dtype=np.float64)[order]
+        with _few_blas_threads():
+            self._update(parents)
+
+    def _update(self, parents):
         old_mean = self.mean
         self.mean = self.weights @ parents
         y_w = (self.mean - old_mean) / self.sigma
