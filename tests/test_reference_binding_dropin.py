@@ -124,6 +124,9 @@ def run_app(name, track, until, timeout=60, cwd=None, may_finish=False, trace=No
     if not os.path.exists(exe):
         pytest.skip("%s not built (needs /root/reference at build time)" % exe)
     env = dict(os.environ)
+    # libtorch's intra-op pool would start a thread per host core for these tiny networks; their spin-waiting eats a container's
+    # CPU quota (the whole process is then paused until the next scheduler period)
+    env.setdefault("OMP_NUM_THREADS", "4")
     if trace:
         env.update(OKENV_TRACE_FILE=trace, OKENV_TRACE_STEPS="4000")
     log = (trace or os.path.join(cwd or "/tmp", name)) + ".log"
