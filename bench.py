@@ -200,7 +200,7 @@ def bench_evolution(args, ok, torch, dist, rank, world, local_rank, log):
     track = ok.Track(track_name)
     env = ok.BatchedEnvironment.from_track(track, N, R, device=local_rank)
     ga = EvolutionaryRacer(env, track, hidden=30, seed=args.seed + rank, agent_base=rank * N, max_steps=4000,
-                           steps_per_launch=args.steps_per_launch, device=args.tensor_dev)
+                           steps_per_launch=args.steps_per_launch, device=torch.device("cuda", local_rank))  # scores stay on the device whatever the backend
     ga.run_generation()  # warm-up generation (untimed)
     env.sync()
     torch.cuda.synchronize()
@@ -227,7 +227,7 @@ def bench_evolution(args, ok, torch, dist, rank, world, local_rank, log):
                                    % (args.config.upper(), N, R, track_name, ", RCCL fitness all-gather per generation" if world > 1 else ""),
                        "generations": args.generations, "parallelism": "dp%d island populations" % world},
             "generation_wall_s": elapsed_max / args.generations,
-            "generations": [{k: r[k] for k in ("generation", "steps", "rollout_s", "select_mate_s", "island_best", "colony_best")} for r in recs],
+            "generations": [{k: r[k] for k in ("generation", "steps", "rollout_s", "select_mate_s", "island_best", "island_mean", "colony_best", "colony_mean")} for r in recs],
         }), flush=True)
     env.close()
     if world > 1:
@@ -279,6 +279,35 @@ def bench_qlearning(args, ok, torch, dist, rank, world, local_rank, log):
         dist.destroy_process_group()
 
 
+def launch_ranks(n, argv):
+    """Starts `n` ranks of this script (one per GPU) through torch.distributed.run and returns their exit code.  Runs in a
+    process that has not imported torch, let alone touched the GPU; the ranks are fresh children, nothing is exec'ed.  Rank 0's
+    stdout (the ONE JSON line) is relayed as it comes; stderr is shared."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("[bench] --gpus %d without WORLD_SIZE: starting the ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    try:
+        for line in child.stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        return child.wait()
+    except BaseException:
+        child.terminate()  # the exact process we started; torchrun forwards the signal to its ranks
+        child.wait()
+        raise
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,12 +335,26 @@ def main():
                          "kernel trace holds only the timed region's launches)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
+    # ---- --gpus N is a promise: the line printed at the end says n_gpus = N or the run fails ----
+    # Under torchrun (the driver's way of starting N > 1) WORLD_SIZE is set and must equal --gpus.  Started plainly with
+    # --gpus N > 1, this process becomes a launcher: it starts the N ranks itself, BEFORE anything here has touched the GPU
+    # (torch is not even imported yet), relays rank 0's JSON line and exits with the ranks' exit code.
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print("[bench] rank %d: --gpus %d but WORLD_SIZE=%d: refusing to run (the result would carry the wrong n_gpus); start it as "
+              "`python bench.py --gpus %d ...` or under torchrun with --nproc-per-node %d"
+              % (rank, args.gpus, world, args.gpus, args.gpus), file=sys.stderr, flush=True)
+        raise SystemExit(2)
+
+    import torch
+    import torch.distributed as dist
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

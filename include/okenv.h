@@ -289,6 +289,32 @@ OKENV_API int okenv_policy_mlp_set_weights(okenv_t h, const float *in);  /* host
 OKENV_API int okenv_rollout_policy(okenv_t h, int32_t n_steps);
 /* number of agents with crashed_ == false (the loop's all_done test, genetic_learner_sim.cpp:85-92) */
 OKENV_API int okenv_alive_count(okenv_t h, int32_t *out);
+
+/* ---- episodes: "step everybody until every agent has crashed" ----------------------------------------------------
+ * The inner loop of both population callers (EvolutionaryRacer/genetic_learner_sim.cpp:76-95,
+ * RLRacers/Q_Learning/q_racer_sim.cpp:156-190) runs until the step T in which the LAST agent crashes; most agents crash
+ * long before that (a tenth to a fifth of the agent-steps of such a loop belong to agents still alive).  Between
+ * okenv_episode_begin and okenv_episode_end the policy rollouts (okenv_rollout_policy, okenv_rollout_q) therefore
+ *   - step only the agents that can still change: after an agent's first step as a crashed agent nothing about it changes
+ *     any more (it does not move, its standstill counter does not tick, its rays keep their stale hit points, the MLP policy
+ *     sees the same inputs), so it is dropped -- by a wave of the running launch as soon as all its agents are done, and from
+ *     the launch grid by okenv_episode_compact;
+ *   - may overrun T (launches end where the caller's n_steps end): okenv_episode_end finds T and leaves every agent, every
+ *     Q table and the step count exactly as the reference's loop leaves them after step T, whatever the launches' lengths.
+ *     Q-learning's per-step update of CRASHED agents (epsilon-greedy draw + learn with reward -200, q_racer_sim.cpp:158-182)
+ *     is replayed per agent for its steps crash+1 .. T at that point.
+ * Typical loop:   okenv_episode_begin(h);
+ *                 do { okenv_rollout_policy(h, n); okenv_episode_compact(h, &alive, NULL); } while (alive > 0 && more steps allowed);
+ *                 okenv_episode_end(h, &steps, &live);
+ * Needs auto-reset off.  Any call that changes agent state from outside (set/upload/reset/step without a policy) ends the
+ * episode without the end-of-episode corrections. */
+OKENV_API int okenv_episode_begin(okenv_t h);
+/* Rebuilds the list of agents the next rollouts step; *alive_out = agents with crashed_ == false (the loop's all_done test),
+ * *listed_out = agents still stepped (alive ones + those that crashed in the last step taken).  Either may be NULL. */
+OKENV_API int okenv_episode_compact(okenv_t h, int32_t *alive_out, int32_t *listed_out);
+/* *steps_out = T (steps of the reference's loop; all steps taken if somebody is still alive), *live_agent_steps_out = sum over
+ * the steps of the agents that entered the step alive.  Either may be NULL. */
+OKENV_API int okenv_episode_end(okenv_t h, int32_t *steps_out, uint64_t *live_agent_steps_out);
 /* Agent::reset of EVERY agent to one pose (genetic_learner_sim.cpp:65-70) */
 OKENV_API int okenv_reset_all(okenv_t h, float x, float y, float rot_deg);
 /* assignScores (EvolutionaryRacer/MiscUtils.hpp:64-71): score = nearest centre-line index as float, kept on the
@@ -313,7 +339,9 @@ OKENV_API int okenv_q_create(okenv_t h);
 OKENV_API int okenv_q_begin_episode(okenv_t h, int32_t reset_idx);
 /* n_steps x { updateAction (epsilon-greedy, QAgent.hpp:98-119); Environment::step; discretizeState; reward
  * (QAgent.hpp:150-168, nearest centre-line index); learn (QAgent.hpp:121-138) } for every agent, crashed ones included, as
- * q_racer_sim.cpp:158-182 does.  Random draws: Philox keyed (seed; agent_base+i, step_base+s). */
+ * q_racer_sim.cpp:158-182 does.  Random draws: Philox keyed (seed; agent_base+i, step_base+s).  Inside an episode
+ * (okenv_episode_begin) the crashed agents' share of this is deferred to okenv_episode_end, with the same result; epsilon,
+ * seed and agent_base must then stay the same for the whole episode and step_base advance with the steps taken. */
 OKENV_API int okenv_rollout_q(okenv_t h, int32_t n_steps, float epsilon, uint32_t seed, uint32_t agent_base, uint32_t step_base);
 OKENV_API int okenv_q_get_table(okenv_t h, float *out);      /* [N][243][3], host or device pointer */
 OKENV_API int okenv_q_set_table(okenv_t h, const float *in);

@@ -14,6 +14,7 @@
 // (the reference's agent_weights_{1,2}.txt, MiscUtils.hpp:52-59, as one padded block) -- what the parity test replays on
 // the CPU oracle.
 #include <cstdint>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -111,15 +112,22 @@ int main(int argc, char **argv)
         // agent.reset(...) for everybody, then one step for the initial observation (:65-75)
         CHECK(okenv_reset_all(env, start_x, start_y, start_rot));
         CHECK(okenv_step(env, 1));
+        // { updateAction for all; env.step(); all_done? } (:76-93), steps_per_launch iterations per kernel launch, as an episode
+        // (include/okenv.h): only the agents that can still change are stepped, and `iteration` is the reference's own count --
+        // its loop leaves with the step in which the last agent crashes, wherever the launches end
+        CHECK(okenv_episode_begin(env));
         int     iteration = 1;
         int32_t alive     = N;
         while (alive > 0 && iteration < opt.max_steps)
-        { // { updateAction for all; env.step(); all_done? } (:76-93), steps_per_launch iterations per kernel launch
+        {
             const int n = std::min(opt.steps_per_launch, opt.max_steps - iteration);
             CHECK(okenv_rollout_policy(env, n));
             iteration += n;
-            CHECK(okenv_alive_count(env, &alive));
+            CHECK(okenv_episode_compact(env, &alive, nullptr));
         }
+        int32_t loop_steps = 0;
+        CHECK(okenv_episode_end(env, &loop_steps, nullptr));
+        iteration = 1 + loop_steps;
         std::printf("------------ EPISODE %d DONE ---------------\n", episode_idx);
         // assignScores (MiscUtils.hpp:64-71)
         CHECK(okenv_ga_scores(env, scores.data()));

@@ -113,15 +113,23 @@ int main(int argc, char **argv)
         std::printf("------------ EPISODE %d DONE ---------------\neps: %g\n", episode_idx, epsilon);
         // reset, initial observation, current_state_idx_ = discretizeState() (:129-154)
         CHECK(okenv_q_begin_episode(env, reset_idx));
+        // The loop of :156-190 leaves with the step in which the last agent crashes.  Launches of steps_per_launch steps overrun
+        // that step; run as an episode (include/okenv.h) they step only the agents that can still change, and
+        // okenv_episode_end returns the loop's own length and leaves agents and tables as the loop does -- a crashed agent's
+        // per-step draw and -200 update (:158-182) are made there, up to that last step and not beyond.
+        CHECK(okenv_episode_begin(env));
         int     steps = 0;
         int32_t alive = N;
         while (alive > 0 && steps < opt.max_steps)
-        { // :156-190, steps_per_launch iterations of the loop body per kernel launch
+        {
             const int n = std::min(opt.steps_per_launch, opt.max_steps - steps);
             CHECK(okenv_rollout_q(env, n, epsilon, opt.seed, 0, steps_total + static_cast<uint32_t>(steps)));
             steps += n;
-            CHECK(okenv_alive_count(env, &alive));
+            CHECK(okenv_episode_compact(env, &alive, nullptr));
         }
+        int32_t loop_steps = 0;
+        CHECK(okenv_episode_end(env, &loop_steps, nullptr));
+        steps = loop_steps;
         steps_total += static_cast<uint32_t>(steps);
         if (dump)
         {

@@ -33,6 +33,18 @@ struct EventPair
 {
     hipEvent_t start, stop;
 };
+
+// spin-wait hint of the host loops that watch a word in mapped memory
+inline void okCpuRelax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::atomic_signal_fence(std::memory_order_seq_cst);
+#endif
+}
 } // namespace
 
 struct okenv
@@ -88,6 +100,18 @@ struct okenv
     bool      cl_dirty{true};
     int      q_ray[5]{0, 0, 0, 0, 0};
     float    q_epsilon{0.F};
+    // episodes (okenv_episode_begin / _compact / _end)
+    bool      episode{false};
+    int       n_active{-1};       // agents listed for the policy rollouts (-1: everybody, no list)
+    int       ep_kind{0};         // policy of the episode's rollouts: 0 none yet, kPolicyMlp, kPolicyQ
+    uint32_t  ep_steps{0};        // steps taken since okenv_episode_begin
+    uint32_t  ep_q_seed{0}, ep_q_agent_base{0}, ep_q_step_base{0}; // Q-learning: the draws' key, global step of episode step 1
+    float     ep_q_epsilon{0.F};
+    int32_t  *d_active{nullptr}, *d_ep_counts{nullptr}, *d_q_next_state{nullptr};
+    uint8_t  *d_settled{nullptr};
+    uint32_t *d_crash_step{nullptr}, *d_ep_out{nullptr};
+    float    *d_crash_thr{nullptr}, *d_crash_steer{nullptr};
+    unsigned long long *d_live{nullptr};
     std::vector<float> host_cx, host_cy, host_chead, host_ray_deg;
     bool        coop{false};        // cooperative two-phase kernel (LDS form, one ray per lane)
     int         agents_per_block{0}; // coop, tiny populations: agents per workgroup (the other lanes only stage); 0 = dense
@@ -260,7 +284,31 @@ OkStepParams baseParams(okenv *h)
     p.q_epsilon = h->q_epsilon;
     p.cl_start  = h->cl_dirty ? nullptr : h->d_cl_start;
     p.cl_idx    = h->cl_dirty ? nullptr : h->d_cl_idx;
+    if (h->episode)
+    { // read by the policy kernels only
+        p.settled      = h->d_settled;
+        p.crash_step   = h->d_crash_step;
+        p.crash_thr    = h->d_crash_thr;
+        p.crash_steer  = h->d_crash_steer;
+        p.live         = h->d_live;
+        p.q_next_state = h->d_q_next_state;
+        p.ep_step0     = h->ep_steps;
+        if (h->n_active >= 0)
+        {
+            p.active           = h->d_active;
+            p.n_active         = h->n_active;
+            p.agents_per_block = 0; // listed agents are packed densely
+        }
+    }
     return p;
+}
+
+// An episode ends without its end-of-episode corrections when agent state is changed from outside the policy rollouts.
+void dropEpisode(okenv *h)
+{
+    h->episode  = false;
+    h->n_active = -1;
+    h->ep_kind  = 0;
 }
 
 int beginTiming(okenv *h, EventPair *ev)
@@ -476,13 +524,17 @@ int stepResident(okenv *h, const okenv_agent_record *in, volatile uint32_t *slot
         {
             answered = *done_word == seq;
             if (!answered)
-                __builtin_ia32_pause();
+                okCpuRelax();
         }
         if (answered)
             break;
         // (a kernel launched a moment ago may still be on its way -- the first launch of a process loads the code object -- and
         // its patience only starts when it does)
         const double waited_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_asked).count();
+        // Giving up on a kernel that is merely slow is safe because a packed step is a pure function of the input records: the
+        // resident instantiation (kPacked && kResident) takes ALL agent state from the slot, never advances step_counter[0]
+        // (auto-reset makes a handle ineligible) and writes only the exchange buffers and the per-ray arrays, which the redo
+        // overwrites with the same values.  Anything added to the resident form that accumulates device state breaks this.
         if (waited_us > (just_started ? 2.0e6 : 2.5 * kResidentGapUs))
             break;
         if (just_started && waited_us > 1000.0 && hipStreamQuery(h->resident_stream) != hipErrorNotReady)
@@ -517,7 +569,7 @@ int waitPackedDone(okenv *h, const volatile uint32_t *word, const uint32_t seq)
                 std::atomic_thread_fence(std::memory_order_acquire);
                 return OKENV_OK;
             }
-            __builtin_ia32_pause();
+            okCpuRelax();
         }
         const hipError_t q = hipStreamQuery(h->stream);
         if (q == hipErrorNotReady)
@@ -539,8 +591,16 @@ int launchStep(okenv *h, const OkStepParams &p)
     int       rc = beginTiming(h, &ev);
     if (rc != OKENV_OK)
         return rc;
-    const dim3 grid(h->grid_blocks), block(h->block_threads);
-    const int  policy = p.action_source == kActionsMlpPolicy ? kPolicyMlp : kPolicyNone;
+    dim3      grid(h->grid_blocks), block(h->block_threads);
+    const int policy = p.action_source == kActionsMlpPolicy ? kPolicyMlp : kPolicyNone;
+    if (p.active != nullptr)
+    { // an episode's list: the grid covers the listed agents, spread over the CUs like a population of that size
+        const long lanes = static_cast<long>(p.n_active) * h->G;
+        long       per   = ((((lanes + 255) / 256) + 63) / 64) * 64;
+        per              = per < 256 ? 256 : (per > 1024 ? 1024 : per);
+        block            = dim3(static_cast<unsigned>(per));
+        grid             = dim3(static_cast<unsigned>((lanes + per - 1) / per));
+    }
 #define OK_LAUNCH_GENERIC(MODE, LDS)                                                                                   \
     do                                                                                                                 \
     {                                                                                                                  \
@@ -953,6 +1013,8 @@ extern "C"
     int okenv_set_field(okenv_t h, int32_t field, const void *src)
     {
         OK_QUIESCE(h);
+        if (h)
+            dropEpisode(h);
         if (!h || !src)
             return fail(h, OKENV_ERR_INVALID, "okenv_set_field: NULL argument");
         const FieldDesc d = fieldOf(h, field);
@@ -1012,6 +1074,8 @@ extern "C"
     int okenv_upload_state(okenv_t h, const okenv_state_view *host_view)
     {
         OK_QUIESCE(h);
+        if (h)
+            dropEpisode(h);
         return moveState(h, host_view, true);
     }
 
@@ -1024,6 +1088,8 @@ extern "C"
     int okenv_set_actions(okenv_t h, const float *throttle, const float *steer)
     {
         OK_QUIESCE(h);
+        if (h)
+            dropEpisode(h);
         if (!h || !throttle || !steer)
             return fail(h, OKENV_ERR_INVALID, "okenv_set_actions: NULL argument");
         int rc;
@@ -1036,6 +1102,8 @@ extern "C"
     int okenv_reset_agents(okenv_t h, const int32_t *idx, const float *x, const float *y, const float *rot_deg, int32_t n)
     {
         OK_QUIESCE(h);
+        if (h)
+            dropEpisode(h);
         if (!h || n < 0 || (n > 0 && (!idx || !x || !y || !rot_deg)))
             return fail(h, OKENV_ERR_INVALID, "okenv_reset_agents: bad argument");
         if (n == 0)
@@ -1096,6 +1164,8 @@ extern "C"
     int okenv_reset_random(okenv_t h, const int32_t *idx, int32_t n, uint32_t flags, uint32_t seed, uint32_t epoch, uint32_t agent_base)
     {
         OK_QUIESCE(h);
+        if (h)
+            dropEpisode(h);
         if (!h || n < 0)
             return fail(h, OKENV_ERR_INVALID, "okenv_reset_random: bad argument");
         if (!idx)
@@ -1127,6 +1197,8 @@ extern "C"
     int okenv_set_auto_reset(okenv_t h, int32_t enabled, uint32_t flags, uint32_t seed, uint32_t agent_base)
     {
         OK_QUIESCE(h);
+        if (h)
+            dropEpisode(h);
         if (!h)
             return OKENV_ERR_INVALID;
         uint32_t count = 0;
@@ -1166,6 +1238,8 @@ extern "C"
     int okenv_set_step_count(okenv_t h, uint32_t value)
     {
         OK_QUIESCE(h);
+        if (h)
+            dropEpisode(h);
         if (!h)
             return OKENV_ERR_INVALID;
         h->step_count = value;
@@ -1232,6 +1306,8 @@ extern "C"
     int okenv_step(okenv_t h, int32_t n_steps)
     {
         OK_QUIESCE(h);
+        if (h)
+            dropEpisode(h);
         if (!h || n_steps < 0)
             return fail(h, OKENV_ERR_INVALID, "okenv_step: bad argument");
         if (n_steps == 0)
@@ -1244,6 +1320,8 @@ extern "C"
 
     int okenv_step_packed(okenv_t h, const okenv_agent_record *in, okenv_agent_record *out, float *sensor_hits_xy, uint32_t flags)
     {
+        if (h)
+            dropEpisode(h);
         if (!h || !in || !out || !sensor_hits_xy)
             return fail(h, OKENV_ERR_INVALID, "okenv_step_packed: NULL argument");
         OK_HIP(h, hipSetDevice(h->device));
@@ -1394,6 +1472,8 @@ extern "C"
     int okenv_collide(okenv_t h)
     {
         OK_QUIESCE(h);
+        if (h)
+            dropEpisode(h);
         if (!h)
             return OKENV_ERR_INVALID;
         OkStepParams p = baseParams(h);
@@ -1405,6 +1485,8 @@ extern "C"
     int okenv_rollout_random(okenv_t h, int32_t n_steps, uint32_t seed, uint32_t agent_base, uint32_t step_base)
     {
         OK_QUIESCE(h);
+        if (h)
+            dropEpisode(h);
         if (!h || n_steps < 0)
             return fail(h, OKENV_ERR_INVALID, "okenv_rollout_random: bad argument");
         if (h->P <= 0)
@@ -1424,6 +1506,8 @@ extern "C"
     int okenv_init_bench_state(okenv_t h, uint32_t agent_base, int32_t mode)
     {
         OK_QUIESCE(h);
+        if (h)
+            dropEpisode(h);
         if (!h)
             return OKENV_ERR_INVALID;
         if (h->P <= 0)
@@ -1564,6 +1648,8 @@ extern "C"
     int okenv_controller_act(okenv_t h, float throttle, float steering_scale)
     {
         OK_QUIESCE(h);
+        if (h)
+            dropEpisode(h);
         if (!h || !h->d_ctrl_params)
             return fail(h, OKENV_ERR_STATE, "okenv_controller_act: call okenv_controller_create first");
         OK_HIP(h, hipSetDevice(h->device));
@@ -1628,6 +1714,8 @@ extern "C"
     int okenv_policy_mlp_set_weights(okenv_t h, const float *in)
     {
         OK_QUIESCE(h);
+        if (h)
+            dropEpisode(h);
         if (!h || !in || !h->d_mlp_w)
             return fail(h, OKENV_ERR_STATE, "okenv_policy_mlp_set_weights: no policy");
         int rc = copyAny(h, h->d_mlp_w, in, sizeof(float) * static_cast<size_t>(h->N) * OK_MLP_WEIGHTS(h->R));
@@ -1646,11 +1734,101 @@ extern "C"
             return fail(h, OKENV_ERR_STATE, "okenv_rollout_policy: call okenv_policy_mlp_create first");
         if (n_steps == 0)
             return OKENV_OK;
+        if (h->episode)
+        {
+            if (h->ep_kind != 0 && h->ep_kind != kPolicyMlp)
+                return fail(h, OKENV_ERR_STATE, "okenv_rollout_policy: the running episode belongs to okenv_rollout_q");
+            if ((h->reset_flags & kAutoResetOn) != 0U)
+                return fail(h, OKENV_ERR_STATE, "okenv_rollout_policy: episodes need auto-reset off");
+            h->ep_kind = kPolicyMlp;
+        }
         OkStepParams p  = baseParams(h);
         p.n_steps       = n_steps;
         p.action_source = kActionsMlpPolicy;
-        const int rc    = launchStep(h, p);
+        int rc          = OKENV_OK;
+        if (!(h->episode && h->n_active == 0)) // (nobody left to step: the steps still count)
+            rc = launchStep(h, p);
+        if (rc == OKENV_OK && h->episode)
+            h->ep_steps += static_cast<uint32_t>(n_steps);
         return rc == OKENV_OK ? advanceStepCount(h, n_steps) : rc;
+    }
+
+    int okenv_episode_begin(okenv_t h)
+    {
+        OK_QUIESCE(h);
+        if (!h)
+            return OKENV_ERR_INVALID;
+        if ((h->reset_flags & kAutoResetOn) != 0U)
+            return fail(h, OKENV_ERR_STATE, "okenv_episode_begin: episodes need auto-reset off (a crashed agent stays crashed until the caller resets it)");
+        OK_HIP(h, hipSetDevice(h->device));
+        const size_t N = static_cast<size_t>(h->N);
+        int          rc;
+        if (!h->d_settled)
+        {
+            if ((rc = devAlloc(h, &h->d_settled, N)) || (rc = devAlloc(h, &h->d_crash_step, N)) || (rc = devAlloc(h, &h->d_crash_thr, N)) ||
+                (rc = devAlloc(h, &h->d_crash_steer, N)) || (rc = devAlloc(h, &h->d_active, N)) || (rc = devAlloc(h, &h->d_ep_counts, 2U)) ||
+                (rc = devAlloc(h, &h->d_ep_out, 2U)) || (rc = devAlloc(h, &h->d_live, 1U)) || (rc = devAlloc(h, &h->d_q_next_state, N)))
+                return rc;
+        }
+        hipLaunchKernelGGL(okEpisodeBeginKernel, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->st.crashed, h->d_settled, h->d_crash_step,
+                           h->d_live, h->N);
+        OK_HIP(h, hipGetLastError());
+        h->episode  = true;
+        h->n_active = -1;
+        h->ep_kind  = 0;
+        h->ep_steps = 0U;
+        return OKENV_OK;
+    }
+
+    int okenv_episode_compact(okenv_t h, int32_t *alive_out, int32_t *listed_out)
+    {
+        OK_QUIESCE(h);
+        if (!h || !h->episode)
+            return fail(h, OKENV_ERR_STATE, "okenv_episode_compact: no episode is running (okenv_episode_begin)");
+        OK_HIP(h, hipSetDevice(h->device));
+        hipLaunchKernelGGL(okEpisodeCompactKernel, dim3(1), dim3(1024), 0, h->stream, h->d_settled, h->st.crashed, h->N, h->d_active, h->d_ep_counts);
+        OK_HIP(h, hipGetLastError());
+        int32_t counts[2] = {0, 0};
+        OK_HIP(h, hipMemcpyAsync(counts, h->d_ep_counts, sizeof(counts), hipMemcpyDeviceToHost, h->stream));
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        h->n_active = counts[1];
+        if (alive_out)
+            *alive_out = counts[0];
+        if (listed_out)
+            *listed_out = counts[1];
+        return OKENV_OK;
+    }
+
+    int okenv_episode_end(okenv_t h, int32_t *steps_out, uint64_t *live_agent_steps_out)
+    {
+        OK_QUIESCE(h);
+        if (!h || !h->episode)
+            return fail(h, OKENV_ERR_STATE, "okenv_episode_end: no episode is running (okenv_episode_begin)");
+        OK_HIP(h, hipSetDevice(h->device));
+        const unsigned blocks = static_cast<unsigned>((h->N + 255) / 256);
+        hipLaunchKernelGGL(okEpisodeEndKernel, dim3(1), dim3(1024), 0, h->stream, h->st.crashed, h->d_crash_step, h->N, h->ep_steps, h->d_ep_out);
+        if (h->ep_kind == kPolicyMlp)
+            hipLaunchKernelGGL(okEpisodeFixupKernel, dim3(blocks), dim3(256), 0, h->stream, h->st, h->d_crash_step, h->d_crash_thr, h->d_crash_steer,
+                               h->d_ep_out, h->N);
+        else if (h->ep_kind == kPolicyQ)
+            hipLaunchKernelGGL(okQSettleKernel, dim3(blocks), dim3(256), 0, h->stream, h->st, h->d_q_table, h->d_q_state, h->d_q_action,
+                               h->d_q_next_state, h->d_crash_step, h->d_ep_out, h->N, h->ep_q_seed, h->ep_q_agent_base, h->ep_q_step_base,
+                               h->ep_q_epsilon);
+        OK_HIP(h, hipGetLastError());
+        uint32_t           out[2] = {0U, 0U};
+        unsigned long long live   = 0ULL;
+        OK_HIP(h, hipMemcpyAsync(out, h->d_ep_out, sizeof(out), hipMemcpyDeviceToHost, h->stream));
+        OK_HIP(h, hipMemcpyAsync(&live, h->d_live, sizeof(live), hipMemcpyDeviceToHost, h->stream));
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        // the steps beyond T were taken by nobody who could still move: they do not count
+        if (h->ep_kind == kPolicyMlp)
+            h->step_count -= h->ep_steps - out[0];
+        if (steps_out)
+            *steps_out = static_cast<int32_t>(out[0]);
+        if (live_agent_steps_out)
+            *live_agent_steps_out = live;
+        dropEpisode(h);
+        return OKENV_OK;
     }
 
     int okenv_alive_count(okenv_t h, int32_t *out)
@@ -1678,6 +1856,8 @@ extern "C"
     int okenv_reset_all(okenv_t h, float x, float y, float rot_deg)
     {
         OK_QUIESCE(h);
+        if (h)
+            dropEpisode(h);
         if (!h)
             return OKENV_ERR_INVALID;
         OK_HIP(h, hipSetDevice(h->device));
@@ -1711,6 +1891,8 @@ extern "C"
     int okenv_ga_select_mate(okenv_t h, uint32_t seed, uint32_t generation, uint32_t agent_base, int32_t *parents_out)
     {
         OK_QUIESCE(h);
+        if (h)
+            dropEpisode(h);
         if (!h)
             return OKENV_ERR_INVALID;
         if (!h->d_mlp_w)
@@ -1817,6 +1999,23 @@ extern "C"
         if (brc != OKENV_OK)
             return brc;
         h->q_epsilon    = epsilon;
+        if (h->episode)
+        {
+            if (h->ep_kind != 0 && h->ep_kind != kPolicyQ)
+                return fail(h, OKENV_ERR_STATE, "okenv_rollout_q: the running episode belongs to okenv_rollout_policy");
+            if (h->ep_kind == 0)
+            {
+                h->ep_kind         = kPolicyQ;
+                h->ep_q_seed       = seed;
+                h->ep_q_agent_base = agent_base;
+                h->ep_q_epsilon    = epsilon;
+                h->ep_q_step_base  = step_base - h->ep_steps;
+            }
+            else if (h->ep_q_seed != seed || h->ep_q_agent_base != agent_base || h->ep_q_epsilon != epsilon ||
+                     h->ep_q_step_base + h->ep_steps != step_base)
+                return fail(h, OKENV_ERR_INVALID, "okenv_rollout_q: inside an episode seed, agent_base and epsilon must stay the same and "
+                                                  "step_base advance by the steps taken");
+        }
         OkStepParams p  = baseParams(h);
         p.n_steps       = n_steps;
         p.action_source = kActionsQLearning;
@@ -1824,7 +2023,12 @@ extern "C"
         p.seed          = seed;
         p.agent_base    = agent_base;
         p.step_base     = step_base;
-        return launchStep(h, p);
+        int rc          = OKENV_OK;
+        if (!(h->episode && h->n_active == 0))
+            rc = launchStep(h, p);
+        if (rc == OKENV_OK && h->episode)
+            h->ep_steps += static_cast<uint32_t>(n_steps);
+        return rc;
     }
 
     int okenv_q_get_table(okenv_t h, float *out)
@@ -1842,6 +2046,8 @@ extern "C"
     int okenv_q_set_table(okenv_t h, const float *in)
     {
         OK_QUIESCE(h);
+        if (h)
+            dropEpisode(h);
         if (!h || !in || !h->d_q_table)
             return fail(h, OKENV_ERR_STATE, "okenv_q_set_table: no table");
         int rc = copyAny(h, h->d_q_table, in, sizeof(float) * static_cast<size_t>(h->N) * OK_Q_STATES * OK_Q_ACTIONS);
@@ -1902,6 +2108,8 @@ extern "C"
     int okenv_q_assign_mean(okenv_t h, const float *sum, const float *count)
     {
         OK_QUIESCE(h);
+        if (h)
+            dropEpisode(h);
         if (!h || !h->d_q_table || !sum || !count)
             return fail(h, OKENV_ERR_STATE, "okenv_q_assign_mean: no Q table or NULL argument");
         OK_HIP(h, hipSetDevice(h->device));
@@ -1928,6 +2136,8 @@ extern "C"
     int okenv_q_share_knowledge(okenv_t h)
     {
         OK_QUIESCE(h);
+        if (h)
+            dropEpisode(h);
         float *d  = nullptr;
         int    rc = qSums(h, &d);
         if (rc != OKENV_OK)

@@ -118,6 +118,29 @@ struct OkStepParams
     // (100 MHz ticks) a workgroup waits for work before it leaves
     const uint32_t *slots;
     uint32_t        idle_ticks;
+    // Episodes of the population callers ("step everybody until every agent has crashed", genetic_learner_sim.cpp:75-95,
+    // q_racer_sim.cpp:156-190; host side: okenv_episode_begin / _compact / _end).  Policy kernels only; all nullptr otherwise.
+    //   active / n_active   the agents this launch steps (ascending ids): slot i of the grid holds agent active[i]
+    //   settled             1 = the agent is crashed AND has taken one step as a crashed agent: from then on a step changes nothing
+    //                       about it (it does not move, its DisplacementStats do not tick, its rays keep their stale hit points
+    //                       seen from an origin that no longer moves, the MLP policy sees the same inputs) -- the host drops it from
+    //                       `active`, a wave whose agents are all settled leaves the step loop
+    //   crash_step          episode-local index (1, 2, ...) of the step in which the agent crashed (0: it was crashed when the
+    //                       episode began, 0xFFFFFFFF: not yet); crash_thr / crash_steer: its action in that step.  The reference's
+    //                       loop ends with the step T in which the LAST agent crashes; launches overrun T, and okenv_episode_end puts
+    //                       back what the overrun changed (the action of the agents that crashed in step T)
+    //   live                sum over steps of the agents that entered the step alive (one atomic per agent and launch)
+    //   ep_step0            episode steps taken before this launch
+    //   q_next_state        Q-learning: the state index seen in the crash step (it stays the "next state" of every later step);
+    //                       crashed agents' table updates are NOT made by the step kernel but by okQSettleKernel, once T is known
+    const int32_t      *active;
+    int                 n_active;
+    uint8_t            *settled;
+    uint32_t           *crash_step;
+    float              *crash_thr, *crash_steer;
+    unsigned long long *live;
+    uint32_t            ep_step0;
+    int32_t            *q_next_state;
 };
 
 // sequence numbers of packed steps (host and device count alike): 0 = nothing yet, 0xFFFFFFFF = "leave"
@@ -596,18 +619,27 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
 
     const int  G     = p.G;
     const long gl    = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const int  agent = static_cast<int>(gl / G);
+    const int  slot  = static_cast<int>(gl / G);
     const int  rlane = static_cast<int>(gl % G);
+    // episodes (see OkStepParams): the grid covers the listed agents only; a wave whose agents are all settled stops stepping
+    constexpr bool kEpisodes = kPolicy != kPolicyNone;
+    const bool     episode   = kEpisodes && p.settled != nullptr;
+    const bool     listed    = kEpisodes && p.active != nullptr;
     // Lanes past the last agent stay in the loop (shuffles need the whole group) but never touch memory.
-    const bool agent_ok = agent < p.N;
-    const int  a        = agent_ok ? agent : 0;
+    const bool agent_ok = listed ? slot < p.n_active : slot < p.N;
+    const int  a        = agent_ok ? (listed ? p.active[slot] : slot) : 0;
     OkAgentRegs ag      = okLoadAgent(p.st, a);
     // the policy reads the previous observation of this lane's ray (one ray per lane whenever a policy is attached)
     const bool pol_ray = agent_ok && (rlane < p.R);
     float      last_dist = (kPolicy != kPolicyNone && pol_ray) ? p.st.dist[static_cast<long>(a) * p.R + rlane] : 0.F;
+    bool       settled = !agent_ok || (episode && p.settled[a] != 0);
+    uint32_t   live_n  = 0U;
 
     for (int s = 0; s < p.n_steps; ++s)
     {
+        if (episode && __ballot(!settled) == 0ULL)
+            break;
+        const bool was_crashed = ag.crashed;
         if (kPolicy == kPolicyMlp)
             okPolicyAction(p, a, rlane, G, ag, last_dist, pol_ray);
         float sr, cr;
@@ -648,9 +680,30 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
         min_d2 = okGroupMin(min_d2, G);
         if (min_d2 < OK_CRASH_DIST2)
             ag.crashed = true;
+        if (episode)
+        {
+            if (was_crashed)
+                settled = true;
+            else
+            {
+                ++live_n;
+                if (ag.crashed && agent_ok && rlane == 0)
+                {
+                    p.crash_step[a]  = p.ep_step0 + static_cast<uint32_t>(s) + 1U;
+                    p.crash_thr[a]   = ag.thr;
+                    p.crash_steer[a] = ag.steer;
+                }
+            }
+        }
     }
     if (agent_ok && rlane == 0)
         okStoreAgent(p.st, a, ag);
+    if (episode && agent_ok && rlane == 0)
+    {
+        p.settled[a] = settled ? 1 : 0;
+        if (live_n != 0U)
+            atomicAdd(p.live, static_cast<unsigned long long>(live_n));
+    }
     okFinishLaunch(p);
 }
 
@@ -731,10 +784,14 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
     // lane -> (agent, ray): densely over the grid, or -- tiny populations -- a few agents in the first lanes of every workgroup
     const long gl       = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
     const int  in_block = static_cast<int>(threadIdx.x) / G;
-    const int  agent    = p.agents_per_block > 0 ? static_cast<int>(blockIdx.x) * p.agents_per_block + in_block : static_cast<int>(gl / G);
+    const int  slot     = p.agents_per_block > 0 ? static_cast<int>(blockIdx.x) * p.agents_per_block + in_block : static_cast<int>(gl / G);
     const int  r        = static_cast<int>(gl % G); // blockDim.x is a multiple of G
-    const bool agent_ok = agent < p.N && (p.agents_per_block <= 0 || in_block < p.agents_per_block);
-    const int  a        = agent_ok ? agent : 0;
+    // episodes (policy kernels): the grid covers the agents that are still worth stepping, slot i holds agent active[i]
+    constexpr bool kEpisodes = kPolicy != kPolicyNone;
+    const bool     episode   = kEpisodes && p.settled != nullptr;
+    const bool     listed    = kEpisodes && p.active != nullptr;
+    const bool agent_ok = listed ? slot < p.n_active : (slot < p.N && (p.agents_per_block <= 0 || in_block < p.agents_per_block));
+    const int  a        = agent_ok ? (listed ? p.active[slot] : slot) : 0;
     // Which ray a lane works on.  Normally lane r of the group has ray r.  A group with spare lanes and no phase 1 (policy-free
     // kernels) is dealt out directly instead: ray q gets the `dm` consecutive lanes q * dm .. q * dm + dm - 1, lane j of them walks
     // the j-th of dm intervals of the ray and the first of them (j == 0) does the ray's epilogue -- the same cut as phase 2 makes,
@@ -878,8 +935,16 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
         // waves without a single agent (small populations get workgroups of at least 256 lanes so that the image is staged
         // quickly) have nothing to step
         const int n_steps = (__ballot(agent_ok) != 0ULL) ? p.n_steps : 0;
+        bool      settled = !agent_ok || (episode && p.settled[a] != 0); // episodes: nothing left to do for this lane's agent
+        uint32_t  live_n  = 0U;                                          // steps this agent entered alive
         for (int s = 0; s < n_steps; ++s)
         {
+            // episodes: a wave whose agents are all settled is done with this launch (and with the episode)
+            if (episode && __ballot(!settled) == 0ULL)
+                break;
+            const bool was_crashed = ag.crashed;
+            // Q-learning inside an episode: a crashed agent's action draws and table updates are made by okQSettleKernel
+            const bool q_frozen = kPolicy == kPolicyQ && episode && was_crashed;
 #if OKENV_PRIO == 2
             // A launch ends with its slowest wave, and a wave is slow for many steps in a row (its agent sits where rays are long).
             // Waves of one SIMD share its issue slots: the further a wave lags behind the leader of its SIMD, the higher its
@@ -902,7 +967,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
 #endif
             if (kPolicy == kPolicyMlp)
                 okPolicyAction(p, a, r, G, ag, last_dist, ray_ok);
-            if (kPolicy == kPolicyQ)
+            if (kPolicy == kPolicyQ && !q_frozen)
             { // QLearnAgent::updateAction (QAgent.hpp:98-119) from the carried row of the current state
                 q_action = ok_q_choose_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s), p.q_epsilon,
                                               qc0, qc1, qc2);
@@ -1149,35 +1214,61 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                     }
                 }
                 const int   nearest = (bi == 0x7FFFFFFF) ? 0 : bi;
-                const float reward  = ok_q_reward(ag.crashed ? 1 : 0, nearest, &q_prev, p.P);
-                const float *nrow   = q_row0 + next_state * OK_Q_ACTIONS;
-                const float  n0     = __hip_atomic_load(nrow + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float  n1     = __hip_atomic_load(nrow + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float  n2     = __hip_atomic_load(nrow + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                float        mq     = n0;
-                mq                  = (n1 > mq) ? n1 : mq;
-                mq                  = (n2 > mq) ? n2 : mq;
-                float *cell         = q_row0 + q_state * OK_Q_ACTIONS + q_action;
-                const float old_q   = (q_action == 0) ? qc0 : ((q_action == 1) ? qc1 : qc2);
-                const float new_q   = ok_q_learn(old_q, mq, reward);
-                if (agent_ok && r == 0)
-                    __hip_atomic_store(cell, new_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // the row carried into the next step: the current one with the learned value, or the next state's
-                qc0 = (q_action == 0) ? new_q : qc0;
-                qc1 = (q_action == 1) ? new_q : qc1;
-                qc2 = (q_action == 2) ? new_q : qc2;
-                if (!ag.crashed)
+                if (!q_frozen)
                 {
-                    if (next_state != q_state)
+                    const float reward  = ok_q_reward(ag.crashed ? 1 : 0, nearest, &q_prev, p.P);
+                    const float *nrow   = q_row0 + next_state * OK_Q_ACTIONS;
+                    const float  n0     = __hip_atomic_load(nrow + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float  n1     = __hip_atomic_load(nrow + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float  n2     = __hip_atomic_load(nrow + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    float        mq     = n0;
+                    mq                  = (n1 > mq) ? n1 : mq;
+                    mq                  = (n2 > mq) ? n2 : mq;
+                    float *cell         = q_row0 + q_state * OK_Q_ACTIONS + q_action;
+                    const float old_q   = (q_action == 0) ? qc0 : ((q_action == 1) ? qc1 : qc2);
+                    const float new_q   = ok_q_learn(old_q, mq, reward);
+                    if (agent_ok && r == 0)
+                        __hip_atomic_store(cell, new_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // the row carried into the next step: the current one with the learned value, or the next state's
+                    qc0 = (q_action == 0) ? new_q : qc0;
+                    qc1 = (q_action == 1) ? new_q : qc1;
+                    qc2 = (q_action == 2) ? new_q : qc2;
+                    if (!ag.crashed)
                     {
-                        qc0 = n0;
-                        qc1 = n1;
-                        qc2 = n2;
+                        if (next_state != q_state)
+                        {
+                            qc0 = n0;
+                            qc1 = n1;
+                            qc2 = n2;
+                        }
+                        q_state = next_state;
                     }
-                    q_state = next_state;
+                    else if (episode && agent_ok && r == 0)
+                        p.q_next_state[a] = next_state; // what every later step of this agent will see as its next state
+                }
+            }
+            if (episode)
+            {
+                if (was_crashed)
+                    settled = true; // this was its step as a crashed agent: nothing about it changes from here on
+                else
+                {
+                    ++live_n;
+                    if (ag.crashed && agent_ok && r == 0)
+                    { // crashed in this step (wall or standstill timeout)
+                        p.crash_step[a]  = p.ep_step0 + static_cast<uint32_t>(s) + 1U;
+                        p.crash_thr[a]   = ag.thr;
+                        p.crash_steer[a] = ag.steer;
+                    }
                 }
             }
             OK_STAMP(5);
+        }
+        if (episode && agent_ok && r == 0)
+        {
+            p.settled[a] = settled ? 1 : 0;
+            if (live_n != 0U)
+                atomicAdd(p.live, static_cast<unsigned long long>(live_n));
         }
         if (kPolicy == kPolicyQ && agent_ok && r == 0)
         {
@@ -1726,6 +1817,158 @@ __global__ void okGaMateKernel(const float *w_old, float *w_new, const int32_t *
             out = (ok_u01(r.v[2]) < 0.75F) ? wd : wsub;
     }
     w_new[t] = real ? out : 0.F;
+}
+
+// ---- episodes ("step everybody until every agent has crashed") -----------------------------------------------------------
+// Host side: okenv_episode_begin / okenv_episode_compact / okenv_episode_end (include/okenv.h).
+
+// Start of an episode: nobody is settled; an agent that is crashed already counts as crashed "in step 0".
+__global__ void okEpisodeBeginKernel(const uint8_t *crashed, uint8_t *settled, uint32_t *crash_step, unsigned long long *live, int N)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a == 0)
+        *live = 0ULL;
+    if (a >= N)
+        return;
+    settled[a]    = 0;
+    crash_step[a] = crashed[a] != 0 ? 0U : 0xFFFFFFFFU;
+}
+
+// counts[0] = agents alive, counts[1] = agents listed.  The list of the agents that are not settled yet, ascending; one workgroup
+// (N <= 65535 agents: at most 64 passes of 1024).
+__global__ void __launch_bounds__(1024) okEpisodeCompactKernel(const uint8_t *settled, const uint8_t *crashed, int N, int32_t *active, int32_t *counts)
+{
+    __shared__ int wave_sum[16];
+    __shared__ int base_s, alive_s;
+    if (threadIdx.x == 0)
+    {
+        base_s  = 0;
+        alive_s = 0;
+    }
+    __syncthreads();
+    const int lane = static_cast<int>(threadIdx.x) & 63, wave = static_cast<int>(threadIdx.x) >> 6;
+    for (int i0 = 0; i0 < N; i0 += 1024)
+    {
+        const int  i    = i0 + static_cast<int>(threadIdx.x);
+        const bool keep = i < N && settled[i] == 0;
+        const bool live = i < N && crashed[i] == 0;
+        const unsigned long long mk = __ballot(keep), ml = __ballot(live);
+        if (lane == 0)
+        {
+            wave_sum[wave] = __popcll(mk);
+            if (ml != 0ULL)
+                atomicAdd(&alive_s, __popcll(ml));
+        }
+        __syncthreads();
+        int before = base_s;
+        for (int w = 0; w < wave; ++w)
+            before += wave_sum[w];
+        if (keep)
+            active[before + __popcll(mk & ((1ULL << lane) - 1ULL))] = i;
+        __syncthreads();
+        if (threadIdx.x == 0)
+        {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w)
+                tot += wave_sum[w];
+            base_s += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        counts[0] = alive_s;
+        counts[1] = base_s;
+    }
+}
+
+// out[0] = T, the number of steps the reference's loop takes: it leaves after the step in which the last agent crashes
+// (genetic_learner_sim.cpp:84-92, q_racer_sim.cpp:163-190; at least one step is always taken); when somebody is still alive
+// (the caller's own step cap) every step taken counts.  out[1] = agents alive.  One workgroup.
+__global__ void __launch_bounds__(1024) okEpisodeEndKernel(const uint8_t *crashed, const uint32_t *crash_step, int N, uint32_t steps_taken, uint32_t *out)
+{
+    __shared__ uint32_t s_max, s_alive;
+    if (threadIdx.x == 0)
+    {
+        s_max   = 0U;
+        s_alive = 0U;
+    }
+    __syncthreads();
+    uint32_t m = 0U, alive = 0U;
+    for (int i = threadIdx.x; i < N; i += blockDim.x)
+    {
+        if (crashed[i] == 0)
+            ++alive;
+        else
+            m = crash_step[i] > m ? crash_step[i] : m; // (0xFFFFFFFF cannot occur for a crashed agent: see okenv_episode_begin)
+    }
+    atomicMax(&s_max, m);
+    atomicAdd(&s_alive, alive);
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        uint32_t T = s_alive != 0U ? steps_taken : (s_max < 1U ? 1U : s_max);
+        T          = T > steps_taken ? steps_taken : T;
+        out[0]     = T;
+        out[1]     = s_alive;
+    }
+}
+
+// The launches of an episode overrun T (they end at a launch boundary).  The only thing the overrun changes about an agent is the
+// action of those that crashed in step T itself: the reference never asks their policy again, here they have taken their step as
+// a crashed agent.  Put back the action of step T.  (Agents that crashed before T hold the action the policy gives a crashed
+// agent -- the same in every step after the crash, in the reference's loop as well.)
+__global__ void okEpisodeFixupKernel(OkDeviceState st, const uint32_t *crash_step, const float *crash_thr, const float *crash_steer, const uint32_t *T, int N)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= N || st.crashed[a] == 0 || crash_step[a] != T[0] || crash_step[a] == 0U)
+        return;
+    st.thr[a]   = crash_thr[a];
+    st.steer[a] = crash_steer[a];
+}
+
+// Q-learning: what the reference's loop does with an agent after its crash, up to and including step T (q_racer_sim.cpp:158-182):
+// every step an epsilon-greedy action from the row of its (no longer changing) state, then learn(state, action, -200, next state)
+// with the next state it has seen ever since the crash step.  Only the agent's own table is involved, so the steps c + 1 .. T
+// are replayed here, one thread per agent, once T is known; the step kernel leaves crashed agents' tables alone inside an episode.
+__global__ void okQSettleKernel(OkDeviceState st, float *q_table, const int32_t *q_state, int32_t *q_action, const int32_t *q_next_state,
+                                const uint32_t *crash_step, const uint32_t *T_ptr, int N, uint32_t seed, uint32_t agent_base,
+                                uint32_t step_base, float epsilon)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= N || st.crashed[a] == 0)
+        return;
+    const uint32_t T = T_ptr[0], c = crash_step[a];
+    if (c >= T)
+        return;
+    float *table = q_table + static_cast<size_t>(a) * (OK_Q_STATES * OK_Q_ACTIONS);
+    const int sc = q_state[a];
+    // an agent that was crashed when the episode began (c == 0) sees the state of the initial observation as its next state
+    const int sn = c == 0U ? sc : q_next_state[a];
+    float cur[3], nxt[3];
+    for (int k = 0; k < 3; ++k)
+    {
+        cur[k] = table[sc * OK_Q_ACTIONS + k];
+        nxt[k] = table[sn * OK_Q_ACTIONS + k];
+    }
+    int action = q_action[a];
+    for (uint32_t i = c + 1U; i <= T; ++i)
+    { // episode step i is global step step_base + i - 1 of the Philox stream
+        action          = ok_q_choose_action(seed, agent_base + static_cast<uint32_t>(a), step_base + i - 1U, epsilon, cur[0], cur[1], cur[2]);
+        const float *nx = (sn == sc) ? cur : nxt;
+        float        mq = nx[0];
+        mq              = (nx[1] > mq) ? nx[1] : mq;
+        mq              = (nx[2] > mq) ? nx[2] : mq;
+        const float old_q = (action == 0) ? cur[0] : ((action == 1) ? cur[1] : cur[2]);
+        const float new_q = ok_q_learn(old_q, mq, -200.0F);
+        cur[0]            = (action == 0) ? new_q : cur[0];
+        cur[1]            = (action == 1) ? new_q : cur[1];
+        cur[2]            = (action == 2) ? new_q : cur[2];
+    }
+    for (int k = 0; k < 3; ++k)
+        table[sc * OK_Q_ACTIONS + k] = cur[k];
+    q_action[a] = action;
+    ok_q_action_values(action, &st.thr[a], &st.steer[a]);
 }
 
 // ---- RLRacers/Q_Learning service kernels ----------------------------------------------------------------------

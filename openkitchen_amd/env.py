@@ -294,6 +294,22 @@ class BatchedEnvironment:
         capi.check(self._L.okenv_alive_count(self._h, C.byref(n)), self._h)
         return n.value
 
+    # ---- episodes: step everybody until every agent has crashed, at the cost of the agents still alive (include/okenv.h) ----
+    def episode_begin(self):
+        capi.check(self._L.okenv_episode_begin(self._h), self._h)
+
+    def episode_compact(self):
+        """(agents alive, agents still stepped) -- also shrinks the grid of the next rollouts to the latter."""
+        alive, listed = C.c_int32(), C.c_int32()
+        capi.check(self._L.okenv_episode_compact(self._h, C.byref(alive), C.byref(listed)), self._h)
+        return alive.value, listed.value
+
+    def episode_end(self):
+        """(steps of the reference's loop, live agent-steps); leaves the state as that loop leaves it."""
+        steps, live = C.c_int32(), C.c_uint64()
+        capi.check(self._L.okenv_episode_end(self._h, C.byref(steps), C.byref(live)), self._h)
+        return steps.value, live.value
+
     def reset_all(self, x, y, rot_deg):
         capi.check(self._L.okenv_reset_all(self._h, float(x), float(y), float(rot_deg)), self._h)
 

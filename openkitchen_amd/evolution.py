@@ -27,20 +27,29 @@ class EvolutionaryRacer:
         self.start = (float(track.x[3]), float(track.y[3]), float(track.heading[0]))  # genetic_learner_sim.cpp:34-36
         self.history = []
         self._fitness = None  # device tensor the scores are written into (GPU runs)
+        self.live_agent_steps = 0
 
     def rollout(self):
-        """Reset everybody to the start line and drive until every agent has crashed or timed out."""
+        """Reset everybody to the start line and drive until every agent has crashed or timed out
+        (genetic_learner_sim.cpp:75-95).  Runs as an episode (include/okenv.h): launches step only the agents that can still
+        change, and the loop's own step count T -- it ends with the step in which the last agent crashes -- comes back from
+        okenv_episode_end whatever the launches' lengths.  Returns the Environment steps taken (initial observation + T)."""
         e = self.env
         e.reset_all(*self.start)
         e.step(1)  # initial observation (genetic_learner_sim.cpp:75)
-        steps = 1
-        while steps < self.max_steps:
-            n = min(self.spl, self.max_steps - steps)
+        e.episode_begin()
+        steps = 0
+        budget = self.max_steps - 1
+        while steps < budget:
+            n = min(self.spl, budget - steps)
             e.rollout_policy(n)
             steps += n
-            if e.alive_count() == 0:
+            alive, _ = e.episode_compact()
+            if alive == 0:
                 break
-        return steps
+        loop_steps, self.live_agent_steps = e.episode_end()
+        self.live_agent_steps += e.N  # everybody takes the initial step
+        return 1 + loop_steps
 
     def run_generation(self):
         t0 = time.perf_counter()
@@ -60,7 +69,8 @@ class EvolutionaryRacer:
         self.env.sync()
         t2 = time.perf_counter()
         stats = torch.stack([local.max(), local.mean(), colony.max(), colony.mean()]).tolist()  # four scalars leave the device
-        rec = {"generation": self.generation, "steps": steps, "rollout_s": t1 - t0, "select_mate_s": t2 - t1,
+        rec = {"generation": self.generation, "steps": steps, "live_agent_steps": int(self.live_agent_steps), "rollout_s": t1 - t0,
+               "select_mate_s": t2 - t1,
                "island_best": stats[0], "island_mean": stats[1], "colony_best": stats[2], "colony_mean": stats[3],
                "parents": [int(v) for v in parents]}
         self.history.append(rec)

@@ -25,17 +25,20 @@ class QLearningRacers:
         e = self.env
         t0 = time.perf_counter()
         e.q_begin_episode(self.reset_idx)
+        e.episode_begin()  # launches step the agents that can still change; crashed agents' -200 updates are settled at the end
         steps = 0
         while steps < self.max_steps:
             n = min(self.spl, self.max_steps - steps)
             e.rollout_q(n, float(self.epsilon), self.seed, self.agent_base, self.steps_total + steps)
             steps += n
-            if e.alive_count() == 0:
+            alive, _ = e.episode_compact()
+            if alive == 0:
                 break
-        e.sync()
+        steps, live = e.episode_end()  # the loop's own length: it ends with the step in which the last agent crashes
         self.steps_total += steps
         # q_racer_sim.cpp:192-210
         self.epsilon = self.epsilon - np.float32(0.05) if self.epsilon > np.float32(0.05) else np.float32(0.0)
         self.reset_idx = int(self._rng.integers(0, self.track.P))
         self.episode += 1
-        return {"episode": self.episode, "steps": steps, "wall_s": time.perf_counter() - t0, "epsilon_next": float(self.epsilon)}
+        return {"episode": self.episode, "steps": steps, "live_agent_steps": int(live), "wall_s": time.perf_counter() - t0,
+                "epsilon_next": float(self.epsilon)}

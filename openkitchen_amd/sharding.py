@@ -62,9 +62,18 @@ def all_gather_fitness(local_fitness):
     """All-gather of the per-rank fitness vector (1-D tensor, same length on every rank).  Returns [world, n]."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local_fitness.unsqueeze(0).clone()
-    flat = torch.empty(dist.get_world_size() * local_fitness.numel(), dtype=local_fitness.dtype, device=local_fitness.device)
+    w, n = dist.get_world_size(), local_fitness.numel()
+    if local_fitness.is_cuda and dist.get_backend() != "nccl":
+        # gloo rehearsal of the GPU path (no RCCL between two ranks on one card): the device tensor is what the product hands
+        # over, only the collective itself goes through a pinned host copy and the gathered matrix returns to the device
+        host = torch.empty(n, dtype=local_fitness.dtype, pin_memory=True)
+        host.copy_(local_fitness.view(-1))
+        flat = torch.empty(w * n, dtype=local_fitness.dtype)
+        dist.all_gather_into_tensor(flat, host)
+        return flat.to(local_fitness.device).view(w, n)
+    flat = torch.empty(w * n, dtype=local_fitness.dtype, device=local_fitness.device)
     dist.all_gather_into_tensor(flat, local_fitness.contiguous().view(-1))
-    return flat.view(dist.get_world_size(), local_fitness.numel())
+    return flat.view(w, n)
 
 
 class ShardedPopulation:

@@ -1,7 +1,8 @@
 """The two applications the north star names, as C++ programs over the C ABI (openkitchen_amd/csrc/apps/, replacing the
 reference's EvolutionaryRacer/genetic_learner_sim.cpp and RLRacers/Q_Learning/q_racer_sim.cpp): built with g++, run on the
 GPU, and their dumped results -- per-generation scores and parents, the best agent's weights; per-episode step counts, the
-final Q tables and agent states -- compared bit for bit with a replay of the same loops on the CPU oracle."""
+final Q tables and agent states -- compared bit for bit with a replay of the REFERENCE's loops on the CPU oracle, one
+Environment::step per iteration (the apps advance many steps per kernel launch; that must not be visible in any result)."""
 import os
 import subprocess
 
@@ -49,10 +50,9 @@ def test_genetic_learner_sim_matches_oracle_replay(gpu, oracle, apps, tmp_path):
         ga.reset_all(*start)
         orc.step(1)
         it = 1
-        while ga.alive_count() > 0 and it < 1500:
-            n = min(spl, 1500 - it)
-            ga.rollout_policy(n)
-            it += n
+        while ga.alive_count() > 0 and it < 1500:  # the reference's loop, one iteration at a time: the app's launches of `spl`
+            ga.rollout_policy(1)                    # steps must not show in its results
+            it += 1
         assert it == steps, g
         want = ga.scores()
         assert np.array_equal(scores.view(np.uint32), want.view(np.uint32)), g
@@ -85,10 +85,9 @@ def test_q_racer_sim_matches_oracle_replay(gpu, oracle, apps, tmp_path, share):
         assert 0 <= reset_idx < t.P and (e > 0 or reset_idx == 3)
         oq.begin_episode(reset_idx)
         done = 0
-        while done < 1200:
-            n = min(spl, 1200 - done)
-            oq.rollout(n, float(eps), seed, 0, steps_total + done)
-            done += n
+        while done < 1200:  # q_racer_sim.cpp:156-190 one iteration at a time: it leaves with the step in which the last agent
+            oq.rollout(1, float(eps), seed, 0, steps_total + done)  # crashes, and so must the app whatever --steps-per-launch is
+            done += 1
             if oracle.lib().oracle_env_alive_count(orc.h) == 0:
                 break
         assert done == steps, e
