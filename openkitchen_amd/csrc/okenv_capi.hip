@@ -6,6 +6,7 @@
 // okenv_create fails with OKENV_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -100,6 +101,8 @@ struct okenv
     bool      cl_dirty{true};
     int      q_ray[5]{0, 0, 0, 0, 0};
     float    q_epsilon{0.F};
+    unsigned long long *d_stamps{nullptr}; // -DOKENV_STAMPS builds: per-wave stamps of the last launch
+    size_t    stamp_waves{0}, stamp_waves_cap{0};
     // episodes (okenv_episode_begin / _compact / _end)
     bool      episode{false};
     int       n_active{-1};       // agents listed for the policy rollouts (-1: everybody, no list)
@@ -584,7 +587,7 @@ int waitPackedDone(okenv *h, const volatile uint32_t *word, const uint32_t seq)
     }
 }
 
-int launchStep(okenv *h, const OkStepParams &p)
+int launchStep(okenv *h, OkStepParams p) // (by value: the diagnostic build adds its stamp buffer)
 {
     OK_HIP(h, hipSetDevice(h->device));
     EventPair ev{};
@@ -593,14 +596,44 @@ int launchStep(okenv *h, const OkStepParams &p)
         return rc;
     dim3      grid(h->grid_blocks), block(h->block_threads);
     const int policy = p.action_source == kActionsMlpPolicy ? kPolicyMlp : kPolicyNone;
+    float phase1 = h->phase1_range;
     if (p.active != nullptr)
     { // an episode's list: the grid covers the listed agents, spread over the CUs like a population of that size
-        const long lanes = static_cast<long>(p.n_active) * h->G;
+        if (p.action_source == kActionsQLearning)
+        { // ... and a list that has become short gets what a population that small gets from okenv_create: wider lane groups
+          // whose spare lanes take intervals of the agent's rays, no phase 1 (16 rays, 64 listed agents: 9.3 against 11.8 us
+          // per step; the fused MLP's steps gain nothing from it and keep their width)
+            int G = h->G;
+            while (G < 64 && static_cast<long>(p.n_active) * (2L * G) <= 131072L)
+                G *= 2;
+            if (G > h->G)
+            {
+                p.G    = G;
+                phase1 = 0.F;
+            }
+        }
+        const long lanes = static_cast<long>(p.n_active) * p.G;
         long       per   = ((((lanes + 255) / 256) + 63) / 64) * 64;
         per              = per < 256 ? 256 : (per > 1024 ? 1024 : per);
         block            = dim3(static_cast<unsigned>(per));
         grid             = dim3(static_cast<unsigned>((lanes + per - 1) / per));
     }
+#if defined(OKENV_STAMPS)
+    { // diagnostic build: stamp space for every wave of THIS launch (the grid differs between populations, lists and forms)
+        const size_t waves = static_cast<size_t>(grid.x) * (block.x / 64U);
+        if (waves > h->stamp_waves_cap)
+        {
+            unsigned long long *d = nullptr;
+            const int           src = devAlloc(h, &d, waves * kStampWords);
+            if (src != OKENV_OK)
+                return src;
+            h->d_stamps        = d;
+            h->stamp_waves_cap = waves;
+        }
+        h->stamp_waves = waves;
+        p.stamps       = h->d_stamps;
+    }
+#endif
 #define OK_LAUNCH_GENERIC(MODE, LDS)                                                                                   \
     do                                                                                                                 \
     {                                                                                                                  \
@@ -617,9 +650,8 @@ int launchStep(okenv *h, const OkStepParams &p)
             const size_t   lds = coopLdsBytes(h);
             const uint32_t off = static_cast<uint32_t>(h->image_bytes);
             if (p.action_source == kActionsQLearning)
-                hipLaunchKernelGGL(okStepCoopKernel<kPolicyQ>, grid, block, lds + qLdsBytes(h), h->stream, p, off,
-                                   h->phase1_range);
-            else if (policy == kPolicyMlp && h->G == 32) // C3 / C4's 32-ray fan: group width a compile-time constant (+3 %)
+                hipLaunchKernelGGL(okStepCoopKernel<kPolicyQ>, grid, block, lds + qLdsBytes(h), h->stream, p, off, phase1);
+            else if (policy == kPolicyMlp && h->G == 32 && h->R == 32) // C3 / C4's fan: group and fan width compile-time constants
                 hipLaunchKernelGGL((okStepCoopKernel<kPolicyMlp, false, false, false, 32>), grid, block, lds, h->stream, p, off, h->phase1_range);
             else if (policy == kPolicyMlp)
                 hipLaunchKernelGGL(okStepCoopKernel<kPolicyMlp>, grid, block, lds, h->stream, p, off, h->phase1_range);
@@ -740,7 +772,11 @@ extern "C"
         bool         fits = false;
         // cell edge: 24 px when a wave holds one agent (all 64 rays leave one origin), 20 px when it holds several (measured:
         // Silverstone / Spa x 64 rays 4 % faster at 24, Monza x 32 rays 6 % faster at 20)
-        const float cell_default = (h->G == 64 && h->rays_per_lane == 1 && num_rays > 32) ? 24.F : OKGRID_DEFAULT_CELL;
+        // (round 3: 16-ray fans four to a wave -- BASELINE config 5 -- 24 px cells with a 32 px phase 1: 15.6 against 16.4 us per step)
+        const bool  narrow16     = h->G == 16 && h->rays_per_lane == 1;
+        const float cell_default = ((h->G == 64 && h->rays_per_lane == 1 && num_rays > 32) || narrow16) ? 24.F : OKGRID_DEFAULT_CELL;
+        if (narrow16)
+            h->phase1_range = 32.F;
         h->grid = okBuildGridAuto(segs, static_cast<size_t>(num_segments), grid_cell > 0.F ? grid_cell : cell_default, kLdsBudget - kLdsReserve,
                                   &fits, &h->poly);
         if (flags & OKENV_FLAG_BRUTE_FORCE)
@@ -794,13 +830,6 @@ extern "C"
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okDebugCastKernel<kGridLds>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->image_bytes)));
         }
-#if defined(OKENV_STAMPS)
-        if (h->grid_mode == kGridLds)
-        { // diagnostic build: d_refs32 doubles as the stamp buffer (6 x u64 per wave)
-            if ((rc = devAlloc(h, &h->d_refs32, static_cast<size_t>(num_agents) * 32U + 1024U)) != OKENV_OK)
-                return fail(nullptr, rc, h->last_error);
-        }
-#endif
         else if (h->grid_mode == kGridGlobal)
         {
             if ((rc = devAlloc(h, &h->d_refs32, h->grid.refs.size())) != OKENV_OK ||
@@ -2287,12 +2316,15 @@ extern "C"
     }
 
 #if defined(OKENV_STAMPS)
+    // stamps of the last step launch: kStampWords words per wave; returns the number of waves copied (<= waves) or an error (< 0)
     __attribute__((visibility("default"))) int okenv_debug_stamps(okenv_t h, unsigned long long *out, int waves)
     {
         OK_QUIESCE(h);
         OK_HIP(h, hipStreamSynchronize(h->stream));
-        OK_HIP(h, hipMemcpy(out, h->d_refs32, sizeof(unsigned long long) * 16U * waves, hipMemcpyDeviceToHost));
-        return OKENV_OK;
+        const size_t n = std::min(static_cast<size_t>(waves < 0 ? 0 : waves), h->stamp_waves);
+        if (n > 0)
+            OK_HIP(h, hipMemcpy(out, h->d_stamps, sizeof(unsigned long long) * kStampWords * n, hipMemcpyDeviceToHost));
+        return static_cast<int>(n);
     }
 #endif
 

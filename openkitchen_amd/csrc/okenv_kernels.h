@@ -133,6 +133,9 @@ struct OkStepParams
     //   ep_step0            episode steps taken before this launch
     //   q_next_state        Q-learning: the state index seen in the crash step (it stays the "next state" of every later step);
     //                       crashed agents' table updates are NOT made by the step kernel but by okQSettleKernel, once T is known
+#if defined(OKENV_STAMPS)
+    unsigned long long *stamps; // diagnostic build: kStampWords words per wave of the launch (host: launchStep sizes it from the grid)
+#endif
     const int32_t      *active;
     int                 n_active;
     uint8_t            *settled;
@@ -151,6 +154,9 @@ __host__ __device__ inline uint32_t okNextPackedSeq(uint32_t s)
 }
 
 constexpr uint32_t kAutoResetOn = 0x80000000U;
+// diagnostic build (-DOKENV_STAMPS), per wave: [0] policy, [1] pre-step, [3] phase 1, [5] phase 2, [6] epilogue (+ Q-learning)
+// shader cycles summed over the launch's steps; [2] / [4] wave start / end on the 100 MHz clock; [8..17] walk-internal stamps
+constexpr int kStampWords = 24;
 
 // Compile-time policy selector of the step kernels, so that the headline path carries no policy registers.
 enum OkPolicyKind : int
@@ -178,6 +184,14 @@ constexpr int kDppXor1       = 0xB1;  // quad_perm [1,0,3,2]
 constexpr int kDppXor2       = 0x4E;  // quad_perm [2,3,0,1]
 constexpr int kDppHalfMirror = 0x141; // lane i <- lane 7 - i of its group of 8
 constexpr int kDppMirror     = 0x140; // lane i <- lane 15 - i of its row
+
+// An index the compiler cannot see through: the addresses formed from it are formed where it is used instead of being kept in
+// registers (or scratch) from the kernel's start.
+__device__ __forceinline__ int okOpaque(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
 
 // min over the G lanes that belong to one agent; every lane of the group receives the result.
 // (a < b ? a : b) keeps the sequential loop's "NaN never wins" behaviour (CollisionChecker.cu:161-164).
@@ -351,8 +365,12 @@ __device__ __forceinline__ OkAgentRegs okLoadAgent(const OkDeviceState &st, cons
     return r;
 }
 
-__device__ __forceinline__ void okStoreAgent(const OkDeviceState &st, const int a, const OkAgentRegs &r)
+__device__ __forceinline__ void okStoreAgent(const OkDeviceState &st, int a, const OkAgentRegs &r)
 {
+    // The write-back happens once per launch, after the step loop.  Without this the compiler keeps the thirteen addresses it
+    // formed for okLoadAgent alive across the loop (26 VGPRs, or -- in the policy kernels, which have none to spare -- scratch);
+    // an index it cannot see through makes it form them again here.
+    asm volatile("" : "+v"(a));
     st.pos_x[a]     = r.pos_x;
     st.pos_y[a]     = r.pos_y;
     st.rot[a]       = r.rot;
@@ -531,10 +549,10 @@ okMlpAction(const OkStepParams &p, const int a, const int rlane, const int G, Ok
     const float  xs  = ray_ok ? dist_self / 200.0F : 0.F;
     const int    own = OK_MLP_HID_PAD / kUnits; // lanes of the group that own hidden units (= min(G, 32))
     const int    ul  = rlane < own ? rlane : own - 1;
-    // Weights stream from L2 / Infinity Cache (5.3 KB per agent and step).  They are fetched sixteen rows at a time before
-    // the multiply-adds that consume them, so that a lane waits for one memory round trip per sixteen terms instead of one
+    // Weights stream from L2 / Infinity Cache (5.3 KB per agent and step).  They are fetched eight rows at a time before
+    // the multiply-adds that consume them, so that a lane waits for one memory round trip per eight terms instead of one
     // per term; the additions keep their order (input 0, 1, 2, ... / hidden unit 0, 1, 2, ...), hence the same bits.
-    constexpr int kAhead = 16;
+    constexpr int kAhead = 8;
     float         h[kUnits];
 #pragma unroll
     for (int u = 0; u < kUnits; ++u)
@@ -576,6 +594,61 @@ okMlpAction(const OkStepParams &p, const int a, const int rlane, const int G, Ok
                 }
         }
     }
+    float zs[OK_MLP_OUT];
+#pragma unroll
+    for (int k = 0; k < OK_MLP_OUT; ++k)
+        zs[k] = __shfl(z, k, G);
+    ok_ga_decode_action(zs, &ag.thr, &ag.steer);
+}
+
+// The same for a fan whose width is known at compile time and a group of >= 32 lanes (one hidden unit per lane).  The lane's
+// column of w1 -- kR + 2 weights that never change during a launch -- is held in registers from the END of one step (requested
+// after the raycast, whose temporaries are dead by then) to the policy at the start of the next: the memory round trip (the
+// weights stream from L2 / Infinity Cache: 43 MB per 8192 agents, more than the L2s hold) runs under the step's epilogue
+// instead of in front of the policy; the output lanes' column of w2 travels with it.  Same terms in the same order as
+// okMlpAction, hence the same bits.
+template <int kR>
+struct OkMlpColumn
+{
+    float w[kR + 2];          // this lane's hidden unit: its weight for every input
+    float v[OK_MLP_HID_PAD];  // this lane's output (lanes 0..5; the others hold a copy of lane 7's): its weight for every hidden unit
+};
+
+template <int kR>
+__device__ __forceinline__ OkMlpColumn<kR> okMlpFetchColumn(const OkStepParams &p, const int a, const int rlane)
+{
+    const float *w1 = p.mlp_w + static_cast<size_t>(a) * OK_MLP_WEIGHTS(kR);
+    const int    ul = rlane < OK_MLP_HID_PAD ? rlane : OK_MLP_HID_PAD - 1;
+    const float *w2 = w1 + (kR + 2) * OK_MLP_HID_PAD;
+    const int    kl = rlane < OK_MLP_OUT_PAD ? rlane : OK_MLP_OUT_PAD - 1;
+    OkMlpColumn<kR> c;
+#pragma unroll
+    for (int j = 0; j < kR + 2; ++j)
+        c.w[j] = w1[j * OK_MLP_HID_PAD + ul];
+#pragma unroll
+    for (int i = 0; i < OK_MLP_HID_PAD; ++i)
+        c.v[i] = w2[i * OK_MLP_OUT_PAD + kl];
+    return c;
+}
+
+template <int kR>
+__device__ __forceinline__ void okMlpActionWide(const OkStepParams &p, const int a, const int rlane, const int G, OkAgentRegs &ag, const float dist_self,
+                                                const bool ray_ok, const OkMlpColumn<kR> col) // by value: stays in registers
+{
+    const float  x0 = ag.speed / 100.0F;
+    const float  x1 = ok_normalize_angle_deg(ag.rot) / 360.0F;
+    const float  xs = ray_ok ? dist_self / 200.0F : 0.F;
+    float        acc = 0.F;
+    acc              = acc + x0 * col.w[0];
+    acc              = acc + x1 * col.w[1];
+#pragma unroll
+    for (int j = 0; j < kR; ++j)
+        acc = acc + __shfl(xs, j, G) * col.w[2 + j];
+    const float h = (acc > 0.F) ? acc : 0.F;
+    float       z = 0.F;
+#pragma unroll
+    for (int i = 0; i < OK_MLP_HID_PAD; ++i)
+        z = z + __shfl(h, i, G) * col.v[i];
     float zs[OK_MLP_OUT];
 #pragma unroll
     for (int k = 0; k < OK_MLP_OUT; ++k)
@@ -653,7 +726,8 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
         {
             const int  r      = rlane + q * G;
             const bool ray_ok = agent_ok && (r < p.R);
-            const long k      = static_cast<long>(a) * p.R + (ray_ok ? r : 0);
+            long       k      = static_cast<long>(a) * p.R + (ray_ok ? r : 0);
+            asm volatile("" : "+v"(k)); // (output addresses formed here, every step, not held across the raycast of the step before)
             float      hx = ox, hy = oy;
             if (ray_ok)
             {
@@ -689,9 +763,10 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
                 ++live_n;
                 if (ag.crashed && agent_ok && rlane == 0)
                 {
-                    p.crash_step[a]  = p.ep_step0 + static_cast<uint32_t>(s) + 1U;
-                    p.crash_thr[a]   = ag.thr;
-                    p.crash_steer[a] = ag.steer;
+                    const int ae      = okOpaque(a);
+                    p.crash_step[ae]  = p.ep_step0 + static_cast<uint32_t>(s) + 1U;
+                    p.crash_thr[ae]   = ag.thr;
+                    p.crash_steer[ae] = ag.steer;
                 }
             }
         }
@@ -700,7 +775,7 @@ __global__ void __launch_bounds__(1024) okStepKernel(const OkStepParams p)
         okStoreAgent(p.st, a, ag);
     if (episode && agent_ok && rlane == 0)
     {
-        p.settled[a] = settled ? 1 : 0;
+        p.settled[okOpaque(a)] = settled ? 1 : 0;
         if (live_n != 0U)
             atomicAdd(p.live, static_cast<unsigned long long>(live_n));
     }
@@ -915,7 +990,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
         }
 
 #if defined(OKENV_STAMPS)
-        unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long wprof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // walk-internal stamps: [0..4] phase 1, [5..9] phase 2
 #define OK_STAMP(i)                                                                                                    \
         do                                                                                                                 \
@@ -935,6 +1010,13 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
         // waves without a single agent (small populations get workgroups of at least 256 lanes so that the image is staged
         // quickly) have nothing to step
         const int n_steps = (__ballot(agent_ok) != 0ULL) ? p.n_steps : 0;
+        // BASELINE configs 3 / 4 (32-ray fan, 32-lane groups): the lane's w1 column travels from the end of a step to the next policy
+        // (the host launches the kG == 32 policy instantiation for 32-ray fans only, so the condition is a compile-time one and the
+        // column is dead across the raycast)
+        constexpr bool wide_mlp = kPolicy == kPolicyMlp && kG == 32;
+        OkMlpColumn<32> mlp_col;
+        if (wide_mlp)
+            mlp_col = okMlpFetchColumn<32>(p, a, r);
         bool      settled = !agent_ok || (episode && p.settled[a] != 0); // episodes: nothing left to do for this lane's agent
         uint32_t  live_n  = 0U;                                          // steps this agent entered alive
         for (int s = 0; s < n_steps; ++s)
@@ -966,13 +1048,19 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
             }
 #endif
             if (kPolicy == kPolicyMlp)
-                okPolicyAction(p, a, r, G, ag, last_dist, ray_ok);
+            {
+                if (wide_mlp)
+                    okMlpActionWide<32>(p, a, r, G, ag, last_dist, ray_ok, mlp_col);
+                else
+                    okPolicyAction(p, a, r, G, ag, last_dist, ray_ok);
+            }
             if (kPolicy == kPolicyQ && !q_frozen)
             { // QLearnAgent::updateAction (QAgent.hpp:98-119) from the carried row of the current state
                 q_action = ok_q_choose_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s), p.q_epsilon,
                                               qc0, qc1, qc2);
                 ok_q_action_values(q_action, &ag.thr, &ag.steer);
             }
+            OK_STAMP(0);
             // Bench driver (kActionsPhiloxReset): an action depends on (seed, agent, step) only, so lane r of the agent's group
             // draws the action of step s_blk + r and one Philox evaluation serves G steps; each step then fetches its own
             // (same draws, same bits as one evaluation per step).
@@ -1004,7 +1092,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
             const float oy     = ag.pos_y + p.sensor_offset * sr;
             const bool  casts  = ray_ok && !ag.crashed;
 
-            OK_STAMP(0);
+            OK_STAMP(1);
             float min_t = OK_SENSOR_RANGE; // the ray's first-hit parameter
             // ---- phase 1: own ray over [0, T1] ----------------------------------------------------------
             bool  unfinished = false;
@@ -1042,7 +1130,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
             }
             else
                 unfinished = casts; // no phase 1 (spare lanes, but a policy that wants ray r on lane r): phase 2 cuts the whole ray
-            OK_STAMP(1);
+            OK_STAMP(3);
             // ---- phase 2: the wave's unfinished rays, cut into m intervals each, over the wave's 64 lanes ------
             const unsigned long long pending = __ballot(unfinished);
             if (pending != 0ULL)
@@ -1104,26 +1192,32 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                 __builtin_amdgcn_s_setprio(0);
 #endif
             }
-            OK_STAMP(3);
+            OK_STAMP(5);
+            if (wide_mlp)
+                mlp_col = okMlpFetchColumn<32>(p, a, r); // for the next step's policy: in flight during the epilogue
 
             // ---- hit point, transform, crash test (CollisionChecker.cu:69-70,144-172) -----------------------------------
             float min_d2 = OK_SENSOR_RANGE * OK_SENSOR_RANGE;
             if (out_ok)
             {
+                // (an index the compiler cannot see through: the five output addresses are formed here, every step, instead of
+                // being held in ten VGPRs across the raycast)
+                long ke = k;
+                asm volatile("" : "+v"(ke));
                 float hx, hy;
                 if (casts)
                 {
                     hx                = ox + min_t * rdx;
                     hy                = oy + min_t * rdy;
-                    p.st.hit_x[k]     = hx;
-                    p.st.hit_y[k]     = hy;
+                    p.st.hit_x[ke]    = hx;
+                    p.st.hit_y[ke]    = hy;
                 }
                 else
                 { // stale world hit point of a crashed agent
-                    hx = p.st.hit_x[k];
-                    hy = p.st.hit_y[k];
+                    hx = p.st.hit_x[ke];
+                    hy = p.st.hit_y[ke];
                 }
-                min_d2 = okRayEpilogue(p.st, k, hx, hy, ox, oy, sr, cr, last_dist, kPacked ? &last_rel_x : nullptr, kPacked ? &last_rel_y : nullptr);
+                min_d2 = okRayEpilogue(p.st, ke, hx, hy, ox, oy, sr, cr, last_dist, kPacked ? &last_rel_x : nullptr, kPacked ? &last_rel_y : nullptr);
                 min_d2 = (min_d2 < OK_SENSOR_RANGE * OK_SENSOR_RANGE) ? min_d2 : OK_SENSOR_RANGE * OK_SENSOR_RANGE;
             }
             min_d2 = okGroupMin(min_d2, G);
@@ -1137,6 +1231,16 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                 {
                     next_state += ok_q_bin(__shfl(last_dist, p.q_ray[i], G)) * mult;
                     mult *= 3;
+                }
+                // The next state's row is asked for NOW: its round trip (the tables are 47.8 MB at C5: Infinity Cache or HBM) runs under
+                // the nearest-index search below instead of after it.
+                float n0 = 0.F, n1 = 0.F, n2 = 0.F;
+                if (!q_frozen)
+                {
+                    const float *nrow = q_row0 + next_state * OK_Q_ACTIONS;
+                    n0                = __hip_atomic_load(nrow + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    n1                = __hip_atomic_load(nrow + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    n2                = __hip_atomic_load(nrow + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 // RaceTrack::findNearestTrackIndexBruteForce.  The centre line is bucketed by grid cell: the agent's lanes look
                 // at the 3 x 3 cells around its position first; if the best point found there is closer than the block's
@@ -1217,10 +1321,6 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                 if (!q_frozen)
                 {
                     const float reward  = ok_q_reward(ag.crashed ? 1 : 0, nearest, &q_prev, p.P);
-                    const float *nrow   = q_row0 + next_state * OK_Q_ACTIONS;
-                    const float  n0     = __hip_atomic_load(nrow + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const float  n1     = __hip_atomic_load(nrow + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const float  n2     = __hip_atomic_load(nrow + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     float        mq     = n0;
                     mq                  = (n1 > mq) ? n1 : mq;
                     mq                  = (n2 > mq) ? n2 : mq;
@@ -1244,7 +1344,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                         q_state = next_state;
                     }
                     else if (episode && agent_ok && r == 0)
-                        p.q_next_state[a] = next_state; // what every later step of this agent will see as its next state
+                        p.q_next_state[okOpaque(a)] = next_state; // what every later step of this agent will see as its next state
                 }
             }
             if (episode)
@@ -1256,37 +1356,40 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                     ++live_n;
                     if (ag.crashed && agent_ok && r == 0)
                     { // crashed in this step (wall or standstill timeout)
-                        p.crash_step[a]  = p.ep_step0 + static_cast<uint32_t>(s) + 1U;
-                        p.crash_thr[a]   = ag.thr;
-                        p.crash_steer[a] = ag.steer;
+                        const int ae      = okOpaque(a);
+                        p.crash_step[ae]  = p.ep_step0 + static_cast<uint32_t>(s) + 1U;
+                        p.crash_thr[ae]   = ag.thr;
+                        p.crash_steer[ae] = ag.steer;
                     }
                 }
             }
-            OK_STAMP(5);
+            OK_STAMP(6);
         }
         if (episode && agent_ok && r == 0)
         {
-            p.settled[a] = settled ? 1 : 0;
+            p.settled[okOpaque(a)] = settled ? 1 : 0;
             if (live_n != 0U)
                 atomicAdd(p.live, static_cast<unsigned long long>(live_n));
         }
         if (kPolicy == kPolicyQ && agent_ok && r == 0)
         {
-            p.q_state[a]    = q_state;
-            p.q_action[a]   = q_action;
-            p.q_prev_idx[a] = q_prev;
+            const int ae     = okOpaque(a);
+            p.q_state[ae]    = q_state;
+            p.q_action[ae]   = q_action;
+            p.q_prev_idx[ae] = q_prev;
         }
 #if defined(OKENV_STAMPS)
         acc[4] = __builtin_amdgcn_s_memrealtime();
-        if ((threadIdx.x & 63) == 0)
-        { // diagnostic build only: per-wave cycle sums go to the (otherwise unused here) rel_x tail... a dedicated buffer
-            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(const_cast<uint32_t *>(p.g_refs32));
+        if ((threadIdx.x & 63) == 0 && p.stamps != nullptr)
+        { // diagnostic build only: per-wave cycle sums
+            unsigned long long *dbg = p.stamps;
             const long          w   = gl >> 6;
-            for (int i = 0; i < 6; ++i)
-                dbg[w * 16 + i] = acc[i];
+            for (int i = 0; i < 8; ++i)
+                dbg[w * kStampWords + i] = acc[i];
         }
+        if (p.stamps != nullptr)
         { // walk-internal stamps of the lane that spent the longest inside the walks (its view has the fewest gaps)
-            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(const_cast<uint32_t *>(p.g_refs32));
+            unsigned long long *dbg = p.stamps;
             const long          w   = gl >> 6;
             unsigned long long  tot = 0;
             for (int i = 0; i < 10; ++i)
@@ -1299,7 +1402,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
             }
             if (tot == best)
                 for (int i = 0; i < 10; ++i)
-                    dbg[w * 16 + 6 + i] = wprof[i];
+                    dbg[w * kStampWords + 8 + i] = wprof[i];
         }
 #endif
         if (agent_ok && r == 0)

@@ -176,6 +176,42 @@ def test_q_episode_equals_reference_loop(gpu, oracle, track_name, N, R, spl):
     dev.close()
 
 
+def test_q_episode_short_list_gets_wider_lane_groups(gpu, oracle, monkeypatch):
+    """a population created with narrow lane groups (as the 16384 agents of BASELINE config 5 are: four agents to a wave) whose
+    list has become short is launched with wider groups and no phase 1; nothing but the time may change"""
+    monkeypatch.setenv("OKENV_LANES_PER_AGENT", "16")
+    t, dev, orc, oq = make_q(gpu, oracle, "Silverstone", 300, 16)
+    monkeypatch.delenv("OKENV_LANES_PER_AGENT")
+    assert dev.info()["lanes_per_agent"] == 16
+    seed, eps, total = 5, np.float32(0.9), 0
+    for episode in range(2):
+        reset_idx = 3 if episode == 0 else 700
+        dev.q_begin_episode(reset_idx)
+        oq.begin_episode(reset_idx)
+        want_steps, want_live = 0, 0
+        while want_steps < 1000:
+            want_live += oracle.lib().oracle_env_alive_count(orc.h)
+            oq.rollout(1, float(eps), seed, 0, total + want_steps)
+            want_steps += 1
+            if oracle.lib().oracle_env_alive_count(orc.h) == 0:
+                break
+        dev.episode_begin()
+        taken = 0
+        while taken < 1000:
+            dev.rollout_q(30, float(eps), seed, 0, total + taken)   # the first launch is the full population's, narrow groups
+            taken += 30
+            alive, listed = dev.episode_compact()
+            if alive == 0:
+                break
+        steps, live = dev.episode_end()
+        assert (steps, live) == (want_steps, want_live)
+        total += steps
+        assert_same_state(dev.snapshot(), orc.snapshot(), "episode %d" % episode)
+        assert np.array_equal(bits(dev.q_table()), bits(oq.table()))
+        eps = eps - np.float32(0.05)
+    dev.close()
+
+
 def test_q_episode_arguments_must_stay_consistent(gpu, oracle):
     t, dev, orc, oq = make_q(gpu, oracle, "Austin", 16, 5)
     dev.q_begin_episode(3)

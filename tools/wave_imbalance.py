@@ -1,7 +1,7 @@
 """Diagnostic (OKENV_STAMPS build): how unevenly the waves of one C2 launch finish.
 
   tools/build_variant.sh stamps -DOKENV_STAMPS && python tools/wave_imbalance.py [steps_per_launch]
-Per wave: in-loop shader cycles by phase (stamps 0 pre-step, 1 phase 1, 3 phase 2, 5 epilogue) and start / end on the
+Per wave: in-loop shader cycles by phase (stamps 0 + 1 policy + pre-step, 3 phase 1, 5 phase 2, 6 epilogue) and start / end on the
 100 MHz real-time clock.  Prints the spread of the per-wave totals and of the per-SIMD sums (waves w, w+4, w+8, w+12 of a
 workgroup share a SIMD), i.e. how much of the launch is tail."""
 import ctypes as C, os, sys
@@ -24,9 +24,9 @@ env.set_timing(True)
 env.rollout_random(spl, 1234, 0, 200)
 ms, n = env.get_timing()
 waves = N
-out = np.zeros((waves, 16), dtype=np.uint64)
-L.okenv_debug_stamps(env._h, out.ctypes.data_as(C.c_void_p), waves)
-cyc = out[:, [0, 1, 3, 5]].astype(np.float64)
+out = np.zeros((waves, 24), dtype=np.uint64)
+assert L.okenv_debug_stamps(env._h, out.ctypes.data_as(C.c_void_p), waves) == waves
+cyc = np.stack([out[:, 0] + out[:, 1], out[:, 3], out[:, 5], out[:, 6]], axis=1).astype(np.float64)
 tot = cyc.sum(axis=1) / spl
 start, end = out[:, 2].astype(np.float64), out[:, 4].astype(np.float64)
 t0 = start.min()
@@ -40,7 +40,7 @@ simd = np.stack([wg[:, i::4].max(axis=1) for i in range(4)], axis=1)
 print("per-SIMD last finisher: mean %.1f p90 %.1f max %.1f us" % (simd.mean(), np.percentile(simd, 90), simd.max()))
 for name, arr in (("phase1", cyc[:, 1] / spl), ("phase2", cyc[:, 2] / spl), ("pre", cyc[:, 0] / spl)):
     print("  %s cycles per step: mean %.0f p10 %.0f p90 %.0f max %.0f" % (name, arr.mean(), np.percentile(arr, 10), np.percentile(arr, 90), arr.max()))
-wp = out[:, 6:16].astype(np.float64) / spl
+wp = out[:, 8:18].astype(np.float64) / spl
 names = ["setup", "cell-entry", "points", "exact", "cell-leave"]
 for ph, off in (("phase1", 0), ("phase2", 5)):
     print("  %s walk internals (busiest lane), cycles per step: %s ; sum %.0f" % (ph, ", ".join("%s %.0f" % (names[i], wp[:, off + i].mean()) for i in range(5)), wp[:, off:off + 5].sum(axis=1).mean()))
