@@ -45,6 +45,110 @@ def algorithmic_bytes_per_agent_step(N, R, S):
     return 44.0 + 36.0 + 4.0 * R + 16.0 * S / N
 
 
+KERNEL_SOURCES = ["openkitchen_amd/csrc/okenv_kernels.h", "openkitchen_amd/csrc/ok_raycast.h", "openkitchen_amd/csrc/ok_grid.h"]
+
+
+def kernel_source_hash(root=ROOT):
+    """sha256 over the step kernel's sources: profiles/hbm_traffic.json records the hash of the sources its counters were
+    collected on, so that counters of an older kernel are never reported as the current kernel's."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(root, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def load_counter_profile(N, R, track_name, path=None, root=ROOT):
+    """(profile dict or None, note or None): the committed PMC figures for this workload, only if they were collected on the
+    kernel sources as they are now."""
+    path = path or os.path.join(root, "profiles", "hbm_traffic.json")
+    try:
+        tj = json.load(open(path))
+    except Exception as e:  # noqa: BLE001
+        return None, "no counter profile (%s)" % type(e).__name__
+    if (tj.get("agents"), tj.get("rays"), tj.get("track")) != (N, R, track_name):
+        return None, "counter profile is for another workload"
+    if tj.get("kernel_source_sha256") != kernel_source_hash(root):
+        return None, "stale_profile: profiles/hbm_traffic.json was collected on other kernel sources (its kernel_source_sha256 differs); rerun tools/pmc_run.sh"
+    return tj, None
+
+
+C3_BYTES_STATE = 44.0 + 36.0  # SURVEY.md section 8d: agent state read + written per agent-step
+
+
+def bench_secondary_configs(args, ok, torch, local_rank, log):
+    """BASELINE configs 3 and 5 inside the default run (rank 0, N=1): one warm + two timed EvolutionaryRacer generations on
+    Monza (8192 x 32 rays, fused MLP policy) and one warm + two timed Q-learning episodes on Silverstone (16384 x 16 rays).
+    `value` counts agents x steps of the reference's loop (every agent is in the loop until the last one has crashed);
+    `live_value` counts only the agent-steps of agents that entered the step alive -- the ones that move, cast rays and read
+    their policy's weights."""
+    from openkitchen_amd.evolution import EvolutionaryRacer
+    from openkitchen_amd.qlearning import QLearningRacers
+    out = {}
+    # ---- C3 ----
+    N, R = 8192, 32
+    track = ok.Track("Monza")
+    env = ok.BatchedEnvironment.from_track(track, N, R, device=local_rank)
+    ga = EvolutionaryRacer(env, track, hidden=30, seed=args.seed, agent_base=0, max_steps=4000, steps_per_launch=args.steps_per_launch,
+                           device=torch.device("cuda", local_rank))
+    ga.run_generation()
+    env.sync()
+    env.set_timing(True)
+    t0 = time.perf_counter()
+    recs = [ga.run_generation() for _ in range(2)]
+    env.sync()
+    dt = time.perf_counter() - t0
+    kernel_ms, launches = env.get_timing()
+    env.set_timing(False)
+    steps = sum(r["steps"] for r in recs)
+    live = sum(r["live_agent_steps"] for r in recs)
+    b_alg = C3_BYTES_STATE + 4.0 * R + 16.0 * track.S / N
+    b_w = 4.0 * ((R + 2) * 30 + 30 * 6)  # the agent's 1200 policy weights, read once per live agent-step when not cached
+    out["c3"] = {
+        "value": N * steps / dt, "live_value": live / dt, "unit": "agent-steps/s", "ms_per_step": dt / steps * 1e3,
+        "generation_ms": [1e3 * (r["rollout_s"] + r["select_mate_s"]) for r in recs], "steps": [r["steps"] for r in recs],
+        "live_fraction": live / float(N * steps), "kernel_ms_step_launches": kernel_ms, "launches": int(launches),
+        "workload": "C3: EvolutionaryRacer, %d agents x %d rays, Monza.csv, fused 34-30-6 MLP policy + Environment::step, rollout until all "
+                    "crashed, score, select top-5, mate; 2 generations after 1 warm-up" % (N, R),
+        "roofline": {"bound": "hbm", "algorithmic_bytes_per_agent_step": b_alg + b_w, "of_which_policy_weights": b_w,
+                     "achieved": (b_alg + b_w) * live / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (b_alg + b_w) * live / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else None,
+                     "note": "bytes of LIVE agent-steps (crashed agents are not stepped) over the step launches' HIP-event time"}}
+    env.close()
+    # ---- C5 ----
+    N, R = 16384, 16
+    track = ok.Track("Silverstone")
+    env = ok.BatchedEnvironment.from_track(track, N, R, device=local_rank)
+    ql = QLearningRacers(env, track, seed=args.seed, agent_base=0, steps_per_launch=args.steps_per_launch)
+    ql.run_episode()
+    env.sync()
+    env.set_timing(True)
+    t0 = time.perf_counter()
+    recs = [ql.run_episode() for _ in range(2)]
+    env.sync()
+    dt = time.perf_counter() - t0
+    kernel_ms, launches = env.get_timing()
+    env.set_timing(False)
+    steps = sum(r["steps"] for r in recs)
+    live = sum(r["live_agent_steps"] for r in recs)
+    b_alg = C3_BYTES_STATE + 4.0 * R + 16.0 * track.S / N + 2 * 12.0 + 4.0  # + two table rows read, one entry written
+    out["c5"] = {
+        "value": N * steps / dt, "live_value": live / dt, "unit": "agent-steps/s", "ms_per_step": dt / steps * 1e3,
+        "episode_ms": [1e3 * r["wall_s"] for r in recs], "steps": [r["steps"] for r in recs], "live_fraction": live / float(N * steps),
+        "kernel_ms_step_launches": kernel_ms, "launches": int(launches),
+        "workload": "C5: tabular Q-learning, %d agents x %d rays, Silverstone.csv, epsilon-greedy + reward + Q update fused into the step "
+                    "kernel, 243x3 table per agent; 2 episodes after 1 warm-up" % (N, R),
+        "roofline": {"bound": "hbm", "algorithmic_bytes_per_agent_step": b_alg,
+                     "achieved": b_alg * live / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": b_alg * live / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else None,
+                     "note": "bytes of LIVE agent-steps over the step launches' HIP-event time"}}
+    env.close()
+    log("secondary configs: c3 %.3e (live %.3e) agent-steps/s, c5 %.3e (live %.3e)" %
+        (out["c3"]["value"], out["c3"]["live_value"], out["c5"]["value"], out["c5"]["live_value"]))
+    return out
+
+
 def cpu_baseline(track_name, R, seed, log):
     """Times the oracle on this host.  Only rank 0 at N=1 calls this; ~10-30 s of CPU work in total."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -213,13 +317,16 @@ def bench_evolution(args, ok, torch, dist, rank, world, local_rank, log):
     sharding.barrier(device_ids=[local_rank])
     elapsed_max = sharding.max_over_ranks(elapsed, device=args.tensor_dev)
     steps = sum(r["steps"] for r in recs)
-    steps_t = torch.tensor([float(steps)], dtype=torch.float64, device=args.tensor_dev)
+    steps_t = torch.tensor([float(steps), float(sum(r["live_agent_steps"] for r in recs))], dtype=torch.float64, device=args.tensor_dev)
     if world > 1:
         dist.all_reduce(steps_t)
     if rank == 0:
-        total_agent_steps = N * float(steps_t.item())
+        total_agent_steps = N * float(steps_t[0].item())
         print(json.dumps({
             "metric": "agent-steps/sec", "value": total_agent_steps / elapsed_max, "unit": "agent-steps/s", "n_gpus": world,
+            # agents x steps of the reference's loop (everybody is in it until the last agent has crashed); live_value counts the
+            # agent-steps of agents that entered the step alive -- what is actually stepped
+            "live_value": float(steps_t[1].item()) / elapsed_max, "live_fraction": float(steps_t[1].item()) / total_agent_steps,
             "steps": steps, "warmup": recs[0]["steps"], "ms_per_step": elapsed_max / max(steps, 1) * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: EvolutionaryRacer, %d agents x %d rays per GPU, %s.csv, fused 34-30-6 MLP policy + step, "
@@ -227,7 +334,7 @@ def bench_evolution(args, ok, torch, dist, rank, world, local_rank, log):
                                    % (args.config.upper(), N, R, track_name, ", RCCL fitness all-gather per generation" if world > 1 else ""),
                        "generations": args.generations, "parallelism": "dp%d island populations" % world},
             "generation_wall_s": elapsed_max / args.generations,
-            "generations": [{k: r[k] for k in ("generation", "steps", "rollout_s", "select_mate_s", "island_best", "island_mean", "colony_best", "colony_mean")} for r in recs],
+            "generations": [{k: r[k] for k in ("generation", "steps", "live_agent_steps", "rollout_s", "select_mate_s", "island_best", "island_mean", "colony_best", "colony_mean")} for r in recs],
         }), flush=True)
     env.close()
     if world > 1:
@@ -259,13 +366,14 @@ def bench_qlearning(args, ok, torch, dist, rank, world, local_rank, log):
     elapsed = time.perf_counter() - t0
     sharding.barrier(device_ids=[local_rank])
     elapsed_max = sharding.max_over_ranks(elapsed, device=args.tensor_dev)
-    steps_t = torch.tensor([float(steps)], dtype=torch.float64, device=args.tensor_dev)
+    steps_t = torch.tensor([float(steps), float(sum(r["live_agent_steps"] for r in recs))], dtype=torch.float64, device=args.tensor_dev)
     if world > 1:
         dist.all_reduce(steps_t)
     if rank == 0:
         table = env.q_table()
         print(json.dumps({
-            "metric": "agent-steps/sec", "value": N * float(steps_t.item()) / elapsed_max, "unit": "agent-steps/s", "n_gpus": world,
+            "metric": "agent-steps/sec", "value": N * float(steps_t[0].item()) / elapsed_max, "unit": "agent-steps/s", "n_gpus": world,
+            "live_value": float(steps_t[1].item()) / elapsed_max, "live_fraction": float(steps_t[1].item()) / (N * float(steps_t[0].item())),
             "steps": steps, "warmup": 0, "ms_per_step": elapsed_max / max(steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C5: tabular Q-learning, %d agents x %d rays per GPU, %s.csv, epsilon-greedy + reward + Q update fused into "
@@ -452,6 +560,13 @@ def main():
 
     state = env.snapshot()
     crashed_frac = float(state["crashed"].mean())
+    work = None
+    try:  # what the broad phase leaves of the reference's R x S tests per agent-step, at the population's poses right now
+        ws = env.work_stats()
+        if ws["rays"] > 0:
+            work = {k: ws[k] / float(ws["rays"]) for k in ("tests", "cells", "points")}
+    except Exception as e:  # noqa: BLE001
+        log("work stats unavailable: %s" % e)
     callers = None
     if rank == 0 and world == 1 and not args.headline_only:
         try:  # secondary figures must never cost the headline line
@@ -470,10 +585,12 @@ def main():
         achieved_gbs = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         kernel_us_per_step = kernel_ms * 1e3 / (repeats * args.steps)
         traffic, valu = None, None
-        try:  # measured HBM bytes and issue statistics from the committed PMC profile of this kernel, kept PER AGENT-STEP so
-            # that they apply to any --steps / --steps-per-launch; only the workload has to match
-            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-            if (tj["agents"], tj["rays"], tj["track"]) == (N, R, args.track):
+        # measured HBM bytes and issue statistics from the committed PMC profile of this kernel, kept PER AGENT-STEP so that they
+        # apply to any --steps / --steps-per-launch; the workload has to match and so do the kernel's sources (a profile of an
+        # older kernel is reported as stale, never as current)
+        tj, profile_note = load_counter_profile(N, R, args.track)
+        try:
+            if tj is not None:
                 traffic = tj["hbm_bytes_per_agent_step"] * N * steps_per_launch_avg
                 w = tj["per_wave_step"]
                 waves_per_simd = N * info["lanes_per_agent"] / 64.0 / 1024.0
@@ -487,8 +604,15 @@ def main():
                         "wave_time_active_frac": w["active_frac"], "wave_time_wait_frac": w["wait_frac"],
                         "wave_time_issue_stall_frac": w["issue_stall_frac"], "valu_lane_utilisation": w.get("lane_util"),
                         "source": tj["source"]}
-        except Exception:
-            traffic, valu = None, None
+        except Exception as e:  # noqa: BLE001
+            traffic, valu, profile_note = None, None, "counter profile unreadable (%s)" % type(e).__name__
+        secondary = None
+        if world == 1 and not args.headline_only:
+            try:  # secondary figures must never cost the headline line
+                secondary = bench_secondary_configs(args, ok, torch, local_rank, log)
+            except Exception as e:  # noqa: BLE001
+                secondary = {"error": "%s: %s" % (type(e).__name__, e)}
+                log("secondary configs failed: %s" % secondary["error"])
         result = {
             "metric": "agent-steps/sec",
             "value": value,
@@ -517,6 +641,15 @@ def main():
             # what the reference's sweep would have to evaluate for the same result: every ray against all S segments
             "brute_force_equivalent_ray_segment_tests_per_sec": value * R * track.S,
             "valu_roofline": valu,
+            "counter_profile_note": profile_note,
+            # S_tested = exact ray-segment tests per ray (one whole-ray walk per ray at the final poses; the
+            # cooperative kernel's speculative intervals add to it), valu_fraction = agent-steps/s x R x S_tested x 15 FLOP over
+            # the 157.3 TFLOP/s fp32 vector peak -- the share of the VALU peak the REFERENCE's arithmetic per surviving test takes
+            "broad_phase": None if work is None else {
+                "s_tested_per_ray": work["tests"], "cells_per_ray": work["cells"], "points_per_ray": work["points"],
+                "segments": track.S, "tested_fraction_of_sweep": work["tests"] / track.S,
+                "valu_fraction": value / world * R * work["tests"] * 15.0 / 157.3e12},
+            "configs": secondary,
             "value_one_launch_per_step": (N * one_steps / one_elapsed) if one_steps else None,
             "value_host_boundary_pcie_inclusive": (N * pcie_steps / pcie_elapsed) if pcie_steps else None,
             "crashed_fraction_at_end": crashed_frac,

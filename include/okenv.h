@@ -380,6 +380,12 @@ OKENV_API int okenv_track_queries(okenv_track_t t, const float *qx, const float 
 /* TrackSegments::TrackSegments (Environment/TrackSegments.cu:6-42): 4*P segments, x1,y1,x2,y2 each. */
 OKENV_API int okenv_track_segments(okenv_track_t t, float *out_xyxy);
 
+/* Work the broad phase leaves for the population's current poses (measurement aid: SURVEY.md section 8d's S_tested): every
+ * live agent's rays walked once through the grid; out[0] = rays, out[1] = exact ray-segment tests (the reference's sweep,
+ * Environment/CollisionChecker.cu:49-67, makes num_segments per ray), out[2] = grid cells entered, out[3] = boundary points
+ * evaluated by the skip rule.  LDS form of the grid only. */
+OKENV_API int okenv_work_stats(okenv_t h, uint64_t out[4]);
+
 /* ---- device self-checks used by the parity tests --------------------------------------------------- */
 
 /* ok_sincosf evaluated on the GPU (n values, host pointers). */

@@ -2157,3 +2157,39 @@ okDebugCastKernel(const OkStepParams p, const float *ox, const float *oy, const 
         out_t[i] = okCastRay<kMode>(p, view, ox[i], oy[i], cs, sn);
     }
 }
+
+// Work the broad phase leaves per ray, for the population's CURRENT poses (measurement aid: bench.py's S_tested and SURVEY.md
+// section 8d's valu_fraction): every live agent's rays are walked once, whole (ok_cast_poly_interval<true>), and the exact tests,
+// grid cells and boundary points they meet are summed.  out[0] rays, [1] exact ray-segment tests, [2] cells, [3] points.
+__global__ void __launch_bounds__(1024) okWorkStatsKernel(const OkStepParams p, unsigned long long *out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
+    okStageImage(p, ok_lds);
+    OkPolyView view{};
+    view.g        = p.geom;
+    view.slots    = reinterpret_cast<const OkPoint *>(ok_lds);
+    view.hdr      = reinterpret_cast<const OkCellHdr *>(ok_lds + p.off_hdr);
+    view.side_tol = p.side_tol;
+    unsigned long long rays = 0, tests = 0, cells = 0, points = 0;
+    const long         total = static_cast<long>(p.N) * p.R;
+    for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * blockDim.x)
+    {
+        const int a = static_cast<int>(i / p.R), r = static_cast<int>(i % p.R);
+        if (p.st.crashed[a] != 0)
+            continue;
+        float sn, cs, rdy, rdx;
+        ok_sincosf(OK_DEG2RAD * p.st.rot[a], &sn, &cs);
+        ok_sincosf(OK_DEG2RAD * (p.st.rot[a] + p.ray_deg[r]), &rdy, &rdx);
+        const float ox = p.st.pos_x[a] + p.sensor_offset * cs, oy = p.st.pos_y[a] + p.sensor_offset * sn;
+        uint32_t    t = 0, c = 0, pt = 0;
+        (void)ok_cast_poly_interval<true>(view, ox, oy, rdx, rdy, 0.F, OKRC_INF, &t, &c, &pt);
+        rays += 1;
+        tests += t;
+        cells += c;
+        points += pt;
+    }
+    atomicAdd(&out[0], rays);
+    atomicAdd(&out[1], tests);
+    atomicAdd(&out[2], cells);
+    atomicAdd(&out[3], points);
+}

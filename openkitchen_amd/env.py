@@ -370,6 +370,12 @@ class BatchedEnvironment:
         capi.check(self._L.okenv_q_share_knowledge(self._h), self._h)
 
     # ---- measurement / self-checks ------------------------------------------------------------------
+    def work_stats(self):
+        """{rays, tests, cells, points} the broad phase leaves for the current poses (okenv_work_stats)."""
+        out = np.zeros(4, dtype=np.uint64)
+        capi.check(self._L.okenv_work_stats(self._h, capi.ptr(out)), self._h)
+        return dict(zip(("rays", "tests", "cells", "points"), (int(v) for v in out)))
+
     def set_timing(self, enabled):
         capi.check(self._L.okenv_set_timing(self._h, 1 if enabled else 0), self._h)
 

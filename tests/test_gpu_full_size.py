@@ -1,10 +1,18 @@
-"""Size-independent properties at BASELINE.json's full configuration sizes for the caller configurations: C3/C4
-(EvolutionaryRacer, 8192 agents x 32 rays on Monza / Spa) and C5 (Q-learning, 16384 agents x 16 rays).  The oracle cannot
-run these sizes in seconds, so the checks are: a window of the full population equals a small population created with
-that window's global agent ids (which the oracle tests pin bit for bit), launch chunking does not change results, and
-repeated runs are deterministic."""
+"""BASELINE.json's configurations at their FULL sizes, where the machine is full (four waves per SIMD, the wave priorities and the
+inter-wave timing live) and the instantiations the benchmark runs are the ones under test.
+
+C2 (4096 agents x 64 rays, Silverstone, the bench driver's loop) is compared with the oracle directly, every field of every
+agent, bit for bit: the oracle spreads its agents over the host's threads and needs a few seconds for a few dozen steps.
+C3/C4 (EvolutionaryRacer, 8192 x 32 rays) and C5 (Q-learning, 16384 x 16 rays) run whole episodes at full size; the oracle
+replays a WINDOW of the population (agents are independent: a window of the population is the population of that window's
+global agent ids) one Environment::step at a time for as many steps as the device says the full population's loop took.
+Plus the size-independent properties: chunking invariance, determinism, windows against small device populations."""
+import os
+
 import numpy as np
 import pytest
+
+from test_gpu_parity import FIELDS_EXACT, assert_same_state
 
 pytestmark = pytest.mark.gpu
 
@@ -79,3 +87,114 @@ def test_c5_q_learning_window_and_chunking(gpu):
     assert valid.any() and (ta[valid] >= -1200.0).all() and (ta[valid] <= 1200.0).all()
     for x, y in zip(big.q_state(), win.q_state()):
         assert np.array_equal(x[BASE:BASE + W], y)
+
+
+def window(snapshot, lo, n):
+    return {k: v[lo:lo + n] for k, v in snapshot.items()}
+
+
+def test_c2_full_size_equals_oracle(gpu, oracle):
+    """The headline instantiation (okStepCoopKernel<0, false, false, false, 64, true>) with every SIMD holding four waves, against
+    the oracle: from the recipe's initial state through the driver's launches (5 warm-up steps, a 20-step region, ...), and
+    again from the state 400 steps later (the population spread over the track, crashes, re-placements, standstill counters
+    and stale rays in play)."""
+    N, R, seed = 4096, 64, 1234
+    threads = min(os.cpu_count() or 1, 64)
+    t = gpu.Track("Silverstone")
+    fan = gpu.default_ray_fan(R)
+    dev = gpu.BatchedEnvironment.from_track(t, N, num_rays=R)
+    orc = oracle.OracleEnv(t.segments, N, R, fan, (t.x, t.y, t.heading))
+    info = dev.info()
+    assert info["lanes_per_agent"] == 64 and info["grid_in_lds"] == 1 and info["grid_blocks"] * info["block_threads"] == N * 64
+    dev.init_bench_state(0, 0)
+    orc.init_bench_state(0, 0)
+    done = 0
+    for n in (5, 20, 10):  # bench.py --steps 20 --warmup 5: one launch per region
+        dev.rollout_random(n, seed, 0, done)
+        orc.rollout_random(n, seed, 0, done, threads=threads)
+        done += n
+        assert_same_state(dev.snapshot(), orc.snapshot(), "C2 full size after %d steps" % done)
+    for _ in range(4):
+        dev.rollout_random(100, seed, 0, done)
+        done += 100
+    snap = dev.snapshot()
+    assert snap["disp_ctr"].max() > 0 and (snap["crashed"] == 1).any() and np.abs(snap["hit_x"]).max() > 0
+    for f, name in enumerate(gpu.capi.FIELD_NAMES[:19]):
+        orc.set(f, snap[name])
+    for n in (20, 5):
+        dev.rollout_random(n, seed, 0, done)
+        orc.rollout_random(n, seed, 0, done, threads=threads)
+        done += n
+        assert_same_state(dev.snapshot(), orc.snapshot(), "C2 full size after %d steps" % done)
+    dev.close()
+
+
+@pytest.mark.parametrize("track_name", ["Monza", "Spa"])
+def test_c3_c4_full_size_episode_window_equals_oracle(gpu, oracle, track_name):
+    """A whole EvolutionaryRacer rollout of 8192 agents as the product runs it (episode: launches of 100 steps over the agents
+    that can still change), then a window of 96 agents replayed on the oracle one step at a time for the loop's length."""
+    N, R, W, BASE, seed = 8192, 32, 96, 4096 + 64, 1234
+    t = gpu.Track(track_name)
+    start = (float(t.x[3]), float(t.y[3]), float(t.heading[0]))
+    dev = gpu.BatchedEnvironment.from_track(t, N, num_rays=R)
+    dev.set(gpu.capi.F_MODE, np.ones(N, dtype=np.uint8))
+    dev.policy_mlp_create(30, seed, 0)
+    fan = gpu.default_ray_fan(R)
+    orc = oracle.OracleEnv(t.segments, W, R, fan, (t.x, t.y, t.heading))
+    orc.set(oracle.F_MODE, np.ones(W, dtype=np.uint8))
+    ga = oracle.OracleGA(orc, 30, seed, BASE)
+    assert np.array_equal(dev.policy_weights()[BASE:BASE + W].view(np.uint32), ga.weights().view(np.uint32))
+    dev.reset_all(*start)
+    ga.reset_all(*start)
+    dev.step(1)
+    orc.step(1)
+    dev.episode_begin()
+    taken, listed_min = 0, N
+    while taken < 3999:
+        n = min(100, 3999 - taken)
+        dev.rollout_policy(n)
+        taken += n
+        alive, listed = dev.episode_compact()
+        listed_min = min(listed_min, listed)
+        if alive == 0:
+            break
+    steps, live = dev.episode_end()
+    assert 100 < steps <= taken and N < live < N * steps and listed_min < N // 8
+    for _ in range(steps):  # the reference's loop: every agent of the window, crashed or not, until the LAST of the 8192 is done
+        ga.rollout_policy(1)
+    assert_same_state(window(dev.snapshot(), BASE, W), orc.snapshot(), "C3/C4 window after the episode (%d steps)" % steps)
+    assert np.array_equal(dev.ga_scores()[BASE:BASE + W], ga.scores())
+    dev.close()
+
+
+def test_c5_full_size_episode_window_equals_oracle(gpu, oracle):
+    N, R, W, BASE, seed = 16384, 16, 128, 10000, 77
+    t = gpu.Track("Silverstone")
+    dev = gpu.BatchedEnvironment.from_track(t, N, num_rays=R)
+    dev.q_create()
+    fan = gpu.default_ray_fan(R)
+    orc = oracle.OracleEnv(t.segments, W, R, fan, (t.x, t.y, t.heading))
+    oq = oracle.OracleQ(orc)
+    eps, total = np.float32(0.9), 0
+    for episode, reset_idx in enumerate((3, 511)):
+        dev.q_begin_episode(reset_idx)
+        oq.begin_episode(reset_idx)
+        dev.episode_begin()
+        taken = 0
+        while taken < 4000:
+            dev.rollout_q(100, float(eps), seed, 0, total + taken)
+            taken += 100
+            alive, listed = dev.episode_compact()
+            if alive == 0:
+                break
+        steps, live = dev.episode_end()
+        assert 50 < steps <= taken
+        for s in range(steps):
+            oq.rollout(1, float(eps), seed, BASE, total + s)
+        total += steps
+        assert_same_state(window(dev.snapshot(), BASE, W), orc.snapshot(), "C5 window after episode %d (%d steps)" % (episode, steps))
+        assert np.array_equal(dev.q_table()[BASE:BASE + W].view(np.uint32), oq.table().view(np.uint32))
+        for got, want in zip(dev.q_state(), oq.state()):
+            assert np.array_equal(got[BASE:BASE + W], want)
+        eps = eps - np.float32(0.05)
+    dev.close()

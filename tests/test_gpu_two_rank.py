@@ -65,7 +65,9 @@ def test_headline_config_on_two_ranks(gpu):
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 20 and j["repeats"] == 5
     assert j["config"]["global_agents"] == 2 * j["config"]["agents_per_gpu"] == 8192
     assert j["config"]["agent_base_per_rank"] == [0, 4096]
-    assert j["value"] > 1e7 and j["roofline"]["traffic"] is not None
+    assert j["value"] > 1e7
+    # counters come from the committed profile only while it is the current kernel's (tests/test_bench_profile_hash.py)
+    assert (j["roofline"]["traffic"] is not None) != bool(j["counter_profile_note"])
 
 
 def test_island_populations_with_fitness_all_gather_on_two_ranks(gpu):
