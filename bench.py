@@ -305,7 +305,7 @@ def bench_evolution(args, ok, torch, dist, rank, world, local_rank, log):
     env = ok.BatchedEnvironment.from_track(track, N, R, device=local_rank)
     ga = EvolutionaryRacer(env, track, hidden=30, seed=args.seed + rank, agent_base=rank * N, max_steps=4000,
                            steps_per_launch=args.steps_per_launch, device=torch.device("cuda", local_rank))  # scores stay on the device whatever the backend
-    ga.run_generation()  # warm-up generation (untimed)
+    warm = ga.run_generation()  # warm-up generation (untimed)
     env.sync()
     torch.cuda.synchronize()
     sharding.barrier(device_ids=[local_rank])
@@ -334,6 +334,9 @@ def bench_evolution(args, ok, torch, dist, rank, world, local_rank, log):
                                    % (args.config.upper(), N, R, track_name, ", RCCL fitness all-gather per generation" if world > 1 else ""),
                        "generations": args.generations, "parallelism": "dp%d island populations" % world},
             "generation_wall_s": elapsed_max / args.generations,
+            # (for profiles taken over the whole process: rank 0's live agent-steps including the warm-up generation)
+            "rank0_live_agent_steps_with_warmup": int(warm["live_agent_steps"] + sum(r["live_agent_steps"] for r in recs)),
+            "rank0_steps_with_warmup": int(warm["steps"] + steps),
             "generations": [{k: r[k] for k in ("generation", "steps", "live_agent_steps", "rollout_s", "select_mate_s", "island_best", "island_mean", "colony_best", "colony_mean")} for r in recs],
         }), flush=True)
     env.close()
@@ -351,7 +354,7 @@ def bench_qlearning(args, ok, torch, dist, rank, world, local_rank, log):
     track = ok.Track(args.track)
     env = ok.BatchedEnvironment.from_track(track, N, R, device=local_rank)
     ql = QLearningRacers(env, track, seed=args.seed + rank, agent_base=rank * N, steps_per_launch=args.steps_per_launch)
-    ql.run_episode()  # warm-up episode
+    warm = ql.run_episode()  # warm-up episode
     env.sync()
     torch.cuda.synchronize()
     sharding.barrier(device_ids=[local_rank])
@@ -380,6 +383,8 @@ def bench_qlearning(args, ok, torch, dist, rank, world, local_rank, log):
                                    "the step kernel, 243x3 table per agent (%.1f MB)" % (N, R, args.track, N * 243 * 3 * 4 / 1e6),
                        "episodes": len(recs), "parallelism": "dp%d" % world},
             "episodes": recs, "learned_entries_fraction": float((table > -1e30).mean()),
+            "rank0_live_agent_steps_with_warmup": int(warm["live_agent_steps"] + sum(r["live_agent_steps"] for r in recs)),
+            "rank0_steps_with_warmup": int(warm["steps"] + steps),
         }), flush=True)
     env.close()
     if world > 1:
