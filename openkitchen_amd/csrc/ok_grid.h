@@ -19,6 +19,10 @@
 // Default cell edge [px]: 16-24 px perform within a few percent of each other on the config tracks (measured on MI355X);
 // smaller cells mean more cell steps, larger ones more points per cell.
 #define OKGRID_DEFAULT_CELL 20.F
+// 1: the cells' runs start in LDS columns chosen by cell position (okBuildPolyImage); 0: plain cell-major order (ablation)
+#if !defined(OKGRID_ALIGN_COLUMNS)
+#define OKGRID_ALIGN_COLUMNS 1
+#endif
 
 struct OkGridHost
 {
@@ -212,6 +216,7 @@ struct OkPolyImage
     std::vector<uint8_t> bytes;     // slots | hdr, each part 16-byte aligned
     size_t               off_hdr{0};
     uint32_t             max_slots_per_cell{0};
+    uint32_t             pad_slots{0}; // slots spent on starting cells' runs in their LDS columns
     float                side_tol{0.F};
     float                max_seg_len{0.F};
 };
@@ -243,8 +248,46 @@ inline OkPolyImage okBuildPolyImage(const OkSeg *segs, const size_t num_segments
     bool                   encodable = true;
     std::vector<OkPoint>   cs; // the cell's slots before chunking
     std::vector<uint8_t>   cb;
-    for (size_t c = 0; c < ncell; ++c)
+    // Order of the cells' runs in the slot stream.  A lane reads its cell's slots 16 bytes at a time (ds_read_b128), all lanes of
+    // a wave at the same offset into their cells; the LDS serves eight lanes per cycle, without a conflict when their 16-byte
+    // pieces are the same piece or fall into different 16-byte columns of its 128-byte row.  The rays of a fan sit in a few
+    // NEIGHBOURING cells at any time, so cell (cx, cy)'s run is made to start in column (cx + 2 cy) mod 8 -- different for any two
+    // cells of a 3 x 3 block.  The stream is cell-major in no particular order (the headers carry the starts), so this is a
+    // matter of emitting, at every point, a cell that wants the column the stream has reached, and padding (16 bytes per column
+    // skipped) only when no such cell is left.  Cells without segments own no slots.
+    const bool                       align_columns = OKGRID_ALIGN_COLUMNS != 0;
+    std::vector<std::vector<size_t>> want(8);
+    size_t                           to_emit = ncell;
+    if (align_columns)
     {
+        to_emit = 0;
+        for (size_t c = ncell; c-- > 0;) // (descending, so that pop_back hands the cells of a column out in ascending order)
+            if (grid.start[c + 1] > grid.start[c])
+            {
+                want[(c % static_cast<size_t>(grid.g.nx) + 2U * (c / static_cast<size_t>(grid.g.nx))) & 7U].push_back(c);
+                ++to_emit;
+            }
+    }
+    for (size_t step = 0; step < to_emit; ++step)
+    {
+        size_t c = step;
+        if (align_columns)
+        {
+            const size_t col  = (slots.size() / 2U) & 7U;
+            size_t       pick = col;
+            while (want[pick].empty()) // the column reached, else the nearest one ahead (least padding); one is non-empty
+                pick = (pick + 1U) & 7U;
+            c = want[pick].back();
+            want[pick].pop_back();
+            for (size_t pc = col; pc != pick; pc = (pc + 1U) & 7U)
+            { // two slots = one 16-byte column
+                slots.push_back({0.F, 0.F});
+                slots.push_back({0.F, 0.F});
+                brk.push_back(1);
+                brk.push_back(1);
+                img.pad_slots += 2U;
+            }
+        }
         cs.clear();
         cb.clear();
         uint32_t       k     = grid.start[c];
