@@ -103,6 +103,8 @@ struct okenv
     float    q_epsilon{0.F};
     unsigned long long *d_stamps{nullptr}; // -DOKENV_STAMPS builds: per-wave stamps of the last launch
     size_t    stamp_waves{0}, stamp_waves_cap{0};
+    int       tail_max_agents{-1}; // episode lists up to this long are stepped by okStepTailKernel: -1 = what one round of
+                                   // workgroups holds, 0 = never (OKENV_TAIL_MAX_AGENTS)
     // episodes (okenv_episode_begin / _compact / _end)
     bool      episode{false};
     int       n_active{-1};       // agents listed for the policy rollouts (-1: everybody, no list)
@@ -634,6 +636,50 @@ int launchStep(okenv *h, OkStepParams p) // (by value: the diagnostic build adds
         p.stamps       = h->d_stamps;
     }
 #endif
+    // The tail of an episode: a short list is stepped one agent per workgroup, every ray cut into eight intervals
+    // (okStepTailKernel).  Two such workgroups fit a CU's LDS; beyond about two rounds of them the cooperative kernel's shared
+    // waves win again.
+    const bool q_launch = p.action_source == kActionsQLearning;
+    if (p.active != nullptr && h->grid_mode == kGridLds && h->coop && (policy == kPolicyMlp || q_launch) && p.n_active > 0 &&
+        h->tail_max_agents != 0)
+    {
+        const unsigned lanes = static_cast<unsigned>(((h->R * kTailSplit + 63) / 64) * 64);
+        const size_t   lds   = h->image_bytes + 16U + sizeof(float) * kTailLdsFloats + (q_launch ? qLdsBytes(h) : 0U);
+        // one round of workgroups: as many per CU as the LDS holds, 256 CUs (measured, 32-ray MLP agents: 8.5 us per step up to
+        // 256 agents, 10.3 at 512 with two per CU, against 11.2-11.8 for the cooperative kernel; a second round loses: 17 us)
+        const long fit       = lds <= kLdsBudget ? static_cast<long>(kLdsBudget / lds) * 256L : 0L;
+        const long max_tail  = h->tail_max_agents > 0 ? std::min<long>(h->tail_max_agents, fit) : fit;
+        if (lanes <= 512U && p.n_active <= max_tail)
+        {
+            p.G = h->G; // (unused by the tail kernel; undo the widening above)
+            const dim3     tgrid(static_cast<unsigned>(p.n_active)), tblock(lanes);
+            const uint32_t off = static_cast<uint32_t>(h->image_bytes);
+#if defined(OKENV_STAMPS)
+            { // [0] policy, [1] pre-step, [3] interval walk + min, [5] epilogue, [6] barrier, [7] crash test + Q-learning; [2] / [4] start / end
+                const size_t waves = static_cast<size_t>(p.n_active) * (lanes / 64U);
+                if (waves > h->stamp_waves_cap)
+                {
+                    unsigned long long *d = nullptr;
+                    const int           src = devAlloc(h, &d, waves * kStampWords);
+                    if (src != OKENV_OK)
+                        return src;
+                    h->d_stamps        = d;
+                    h->stamp_waves_cap = waves;
+                }
+                h->stamp_waves = waves;
+                p.stamps       = h->d_stamps;
+            }
+#endif
+            if (q_launch)
+                hipLaunchKernelGGL((okStepTailKernel<kPolicyQ, 0>), tgrid, tblock, lds, h->stream, p, off);
+            else if (h->R == 32)
+                hipLaunchKernelGGL((okStepTailKernel<kPolicyMlp, 32>), tgrid, tblock, lds, h->stream, p, off);
+            else
+                hipLaunchKernelGGL((okStepTailKernel<kPolicyMlp, 0>), tgrid, tblock, lds, h->stream, p, off);
+            OK_HIP(h, hipGetLastError());
+            return endTiming(h, ev);
+        }
+    }
 #define OK_LAUNCH_GENERIC(MODE, LDS)                                                                                   \
     do                                                                                                                 \
     {                                                                                                                  \
@@ -827,6 +873,12 @@ extern "C"
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyMlp, false, false, false, 32>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepTailKernel<kPolicyMlp, 32>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepTailKernel<kPolicyMlp, 0>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepTailKernel<kPolicyQ, 0>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okDebugCastKernel<kGridLds>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->image_bytes)));
         }
@@ -894,6 +946,8 @@ extern "C"
             h->resident_stall_us = std::atoi(env_stall);
         if (const char *env_res = std::getenv("OKENV_RESIDENT")) // 0: never keep the packed-step kernel resident, 1: from the first step on
             h->resident_mode = std::atoi(env_res);
+        if (const char *env_tail = std::getenv("OKENV_TAIL_MAX_AGENTS")) // tuning / ablation knob; 0: never use the tail kernel
+            h->tail_max_agents = std::atoi(env_tail);
         if (const char *env_t1 = std::getenv("OKENV_PHASE1_RANGE"))
         {
             const float t1 = static_cast<float>(std::atof(env_t1));

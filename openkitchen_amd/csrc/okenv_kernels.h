@@ -682,6 +682,135 @@ __device__ __forceinline__ OkPolyView okSetupView(const OkStepParams &p, unsigne
     return view;
 }
 
+// ---- RLRacers/Q_Learning pieces shared by the step kernels ------------------------------------------------------------
+
+// What the fused Q-learning carries from step to step in registers: current state / action / previous track index, and the Q
+// values of the current state (the table lives in HBM / Infinity Cache and only this agent's lanes ever touch its part of it, so
+// the row is read once per launch; after a step it is either patched with the value just learned or replaced by the next
+// state's row, which the update reads anyway).
+struct OkQCarry
+{
+    int state, action, prev;
+};
+// (the row's three values travel as separate variables c0, c1, c2: as members of the struct, hipcc turns the selects over them
+// into an indexed load and puts the struct on the stack)
+
+// RaceTrack::findNearestTrackIndexBruteForce (RaceTrack.cpp:16-31) for the position (px, py), by the G lanes of a group (lane r
+// of it calling; every lane receives the result).  The centre line sits in LDS, bucketed by grid cell: the lanes look at the
+// 3 x 3 cells around the position first; if the best point found there is closer than the block's nearest edge, no point
+// outside can beat or tie it and the result is the brute-force argmin (strict '<' per lane over ascending indices, (distance,
+// index) order across lanes: "lowest index wins").  Otherwise -- a position far from the track -- the lanes stride over the
+// whole centre line.
+__device__ __forceinline__ int okNearestBucketed(const OkStepParams &p, const float *lds_cx, const float *lds_cy, const uint16_t *lds_cstart,
+                                                 const uint16_t *lds_cidx, const float px, const float py, const int r, const int G)
+{
+    float best = 3.402823466e+38F;
+    int   bi   = 0x7FFFFFFF;
+    bool  done = false;
+    if (p.cl_start != nullptr)
+    {
+        const OkGridGeom &g  = p.geom;
+        const int         ci = static_cast<int>((px - g.x0) * g.inv_cell), cj = static_cast<int>((py - g.y0) * g.inv_cell);
+        if (px >= g.x0 && py >= g.y0 && ci < g.nx && cj < g.ny)
+        {
+            for (int c = r; c < 9; c += G)
+            {
+                const int ix = ci + (c % 3) - 1, iy = cj + (c / 3) - 1;
+                if (ix < 0 || iy < 0 || ix >= g.nx || iy >= g.ny)
+                    continue;
+                const int cell = iy * g.nx + ix;
+                for (int k = lds_cstart[cell]; k < lds_cstart[cell + 1]; ++k)
+                {
+                    const int   i  = lds_cidx[k];
+                    const float dx = px - lds_cx[i], dy = py - lds_cy[i];
+                    const float d2 = dx * dx + dy * dy;
+                    if (d2 < best)
+                    {
+                        best = d2;
+                        bi   = i;
+                    }
+                }
+            }
+            for (int off = 1; off < G; off <<= 1)
+            {
+                const float ob = __shfl_xor(best, off, 64);
+                const int   oi = __shfl_xor(bi, off, 64);
+                if (ob < best || (ob == best && oi < bi))
+                {
+                    best = ob;
+                    bi   = oi;
+                }
+            }
+            // distance from the position to the nearest edge of the 3 x 3 block (>= one cell), minus slack for the rounding of
+            // the cell arithmetic and of d2
+            const float ex = fminf(px - (g.x0 + static_cast<float>(ci - 1) * g.cell), (g.x0 + static_cast<float>(ci + 2) * g.cell) - px);
+            const float ey = fminf(py - (g.y0 + static_cast<float>(cj - 1) * g.cell), (g.y0 + static_cast<float>(cj + 2) * g.cell) - py);
+            const float m  = fminf(ex, ey) - 0.05F;
+            done           = bi != 0x7FFFFFFF && m > 0.F && best < m * m;
+        }
+    }
+    if (!done)
+    {
+        best = 3.402823466e+38F;
+        bi   = 0x7FFFFFFF;
+        for (int i = r; i < p.P; i += G)
+        {
+            const float dx = px - lds_cx[i], dy = py - lds_cy[i];
+            const float d2 = dx * dx + dy * dy;
+            if (d2 < best)
+            {
+                best = d2;
+                bi   = i;
+            }
+        }
+        for (int off = 1; off < G; off <<= 1)
+        {
+            const float ob = __shfl_xor(best, off, 64);
+            const int   oi = __shfl_xor(bi, off, 64);
+            if (ob < best || (ob == best && oi < bi))
+            {
+                best = ob;
+                bi   = oi;
+            }
+        }
+    }
+    return (bi == 0x7FFFFFFF) ? 0 : bi;
+}
+
+// q_racer_sim.cpp:171-182 for one agent after Environment::step: reward from the progress along the centre line
+// (QAgent.hpp:150-168), learn (QAgent.hpp:121-138) with the next state's row (n0, n1, n2, read by the caller), the carried row
+// moved on.  `writer`: the one lane that stores the learned value.
+__device__ __forceinline__ void okQLearnStep(const OkStepParams &p, float *q_row0, const bool writer, const bool crashed, const int next_state,
+                                             const int nearest, const float n0, const float n1, const float n2, OkQCarry &qs, float &c0, float &c1,
+                                             float &c2)
+{
+    int         prev   = qs.prev; // (a local: the address of a member would put the whole struct on the stack)
+    const float reward = ok_q_reward(crashed ? 1 : 0, nearest, &prev, p.P);
+    qs.prev            = prev;
+    float       mq     = n0;
+    mq                 = (n1 > mq) ? n1 : mq;
+    mq                 = (n2 > mq) ? n2 : mq;
+    float      *cell   = q_row0 + qs.state * OK_Q_ACTIONS + qs.action;
+    const float old_q  = (qs.action == 0) ? c0 : ((qs.action == 1) ? c1 : c2);
+    const float new_q  = ok_q_learn(old_q, mq, reward);
+    if (writer)
+        __hip_atomic_store(cell, new_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the row carried into the next step: the current one with the learned value, or the next state's
+    c0 = (qs.action == 0) ? new_q : c0;
+    c1 = (qs.action == 1) ? new_q : c1;
+    c2 = (qs.action == 2) ? new_q : c2;
+    if (!crashed)
+    {
+        if (next_state != qs.state)
+        {
+            c0 = n0;
+            c1 = n1;
+            c2 = n2;
+        }
+        qs.state = next_state;
+    }
+}
+
 // Generic step kernel: every lane casts its own ray(s) from start to end.  Used for the global-memory and
 // brute-force forms, and for fans wider than 64 rays.
 template <int kMode, int kPolicy>
@@ -966,24 +1095,24 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
         }
         float       last_rel_x = 0.F, last_rel_y = 0.F; // kPacked: sensor_hits_ of the last step
         float       last_dist = (kPolicy != kPolicyNone && ray_ok) ? p.st.dist[k] : 0.F;
-        int         q_state = 0, q_action = 0, q_prev = 0;
+        OkQCarry    qs{};
+        float       qc0 = 0.F, qc1 = 0.F, qc2 = 0.F; // Q values of the agent's current state
         float      *q_row0 = nullptr; // this agent's table
         if (kPolicy == kPolicyQ)
         {
-            q_state  = p.q_state[a];
-            q_action = p.q_action[a];
-            q_prev   = p.q_prev_idx[a];
-            q_row0   = p.q_table + static_cast<size_t>(a) * (OK_Q_STATES * OK_Q_ACTIONS);
+            qs.state  = p.q_state[a];
+            qs.action = p.q_action[a];
+            qs.prev   = p.q_prev_idx[a];
+            q_row0    = p.q_table + static_cast<size_t>(a) * (OK_Q_STATES * OK_Q_ACTIONS);
         }
         // Q values of the agent's current state.  The table (47.8 MB at C5) lives in HBM / Infinity Cache and only this
         // group ever touches this agent's part of it, so the row is read once per launch and then carried in registers:
         // after a step it is either patched with the value just learned or replaced by the next state's row, which the
         // update needs anyway.  One memory round trip per step instead of three; loads and stores stay agent-scope because
         // lane 0 of the group writes what the others have read.
-        float qc0 = 0.F, qc1 = 0.F, qc2 = 0.F;
         if (kPolicy == kPolicyQ)
         {
-            const float *row = q_row0 + q_state * OK_Q_ACTIONS;
+            const float *row = q_row0 + qs.state * OK_Q_ACTIONS;
             qc0              = __hip_atomic_load(row + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             qc1              = __hip_atomic_load(row + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             qc2              = __hip_atomic_load(row + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1056,9 +1185,9 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
             }
             if (kPolicy == kPolicyQ && !q_frozen)
             { // QLearnAgent::updateAction (QAgent.hpp:98-119) from the carried row of the current state
-                q_action = ok_q_choose_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s), p.q_epsilon,
-                                              qc0, qc1, qc2);
-                ok_q_action_values(q_action, &ag.thr, &ag.steer);
+                qs.action = ok_q_choose_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s), p.q_epsilon,
+                                               qc0, qc1, qc2);
+                ok_q_action_values(qs.action, &ag.thr, &ag.steer);
             }
             OK_STAMP(0);
             // Bench driver (kActionsPhiloxReset): an action depends on (seed, agent, step) only, so lane r of the agent's group
@@ -1242,108 +1371,11 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                     n1                = __hip_atomic_load(nrow + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     n2                = __hip_atomic_load(nrow + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                // RaceTrack::findNearestTrackIndexBruteForce.  The centre line is bucketed by grid cell: the agent's lanes look
-                // at the 3 x 3 cells around its position first; if the best point found there is closer than the block's
-                // nearest edge, no point outside can beat or tie it and the result is the brute-force argmin (strict '<' per
-                // lane over ascending indices, (distance, index) order across lanes: "lowest index wins").  Otherwise -- an
-                // agent far from the track -- the lanes stride over the whole centre line as before.
-                float best = 3.402823466e+38F;
-                int   bi   = 0x7FFFFFFF;
-                bool  done = false;
-                if (p.cl_start != nullptr)
-                {
-                    const OkGridGeom &g  = p.geom;
-                    const int         ci = static_cast<int>((ag.pos_x - g.x0) * g.inv_cell), cj = static_cast<int>((ag.pos_y - g.y0) * g.inv_cell);
-                    if (ag.pos_x >= g.x0 && ag.pos_y >= g.y0 && ci < g.nx && cj < g.ny)
-                    {
-                        for (int c = r; c < 9; c += G)
-                        {
-                            const int ix = ci + (c % 3) - 1, iy = cj + (c / 3) - 1;
-                            if (ix < 0 || iy < 0 || ix >= g.nx || iy >= g.ny)
-                                continue;
-                            const int cell = iy * g.nx + ix;
-                            for (int k = lds_cstart[cell]; k < lds_cstart[cell + 1]; ++k)
-                            {
-                                const int   i  = lds_cidx[k];
-                                const float dx = ag.pos_x - lds_cx[i], dy = ag.pos_y - lds_cy[i];
-                                const float d2 = dx * dx + dy * dy;
-                                if (d2 < best)
-                                {
-                                    best = d2;
-                                    bi   = i;
-                                }
-                            }
-                        }
-                        for (int off = 1; off < G; off <<= 1)
-                        {
-                            const float ob = __shfl_xor(best, off, 64);
-                            const int   oi = __shfl_xor(bi, off, 64);
-                            if (ob < best || (ob == best && oi < bi))
-                            {
-                                best = ob;
-                                bi   = oi;
-                            }
-                        }
-                        // distance from the position to the nearest edge of the 3 x 3 block (>= one cell), minus slack for
-                        // the rounding of the cell arithmetic and of d2
-                        const float ex = fminf(ag.pos_x - (g.x0 + static_cast<float>(ci - 1) * g.cell), (g.x0 + static_cast<float>(ci + 2) * g.cell) - ag.pos_x);
-                        const float ey = fminf(ag.pos_y - (g.y0 + static_cast<float>(cj - 1) * g.cell), (g.y0 + static_cast<float>(cj + 2) * g.cell) - ag.pos_y);
-                        const float m  = fminf(ex, ey) - 0.05F;
-                        done           = bi != 0x7FFFFFFF && m > 0.F && best < m * m;
-                    }
-                }
-                if (!done)
-                {
-                    best = 3.402823466e+38F;
-                    bi   = 0x7FFFFFFF;
-                    for (int i = r; i < p.P; i += G)
-                    {
-                        const float dx = ag.pos_x - lds_cx[i], dy = ag.pos_y - lds_cy[i];
-                        const float d2 = dx * dx + dy * dy;
-                        if (d2 < best)
-                        {
-                            best = d2;
-                            bi   = i;
-                        }
-                    }
-                    for (int off = 1; off < G; off <<= 1)
-                    {
-                        const float ob = __shfl_xor(best, off, 64);
-                        const int   oi = __shfl_xor(bi, off, 64);
-                        if (ob < best || (ob == best && oi < bi))
-                        {
-                            best = ob;
-                            bi   = oi;
-                        }
-                    }
-                }
-                const int   nearest = (bi == 0x7FFFFFFF) ? 0 : bi;
+                const int nearest = okNearestBucketed(p, lds_cx, lds_cy, lds_cstart, lds_cidx, ag.pos_x, ag.pos_y, r, G);
                 if (!q_frozen)
                 {
-                    const float reward  = ok_q_reward(ag.crashed ? 1 : 0, nearest, &q_prev, p.P);
-                    float        mq     = n0;
-                    mq                  = (n1 > mq) ? n1 : mq;
-                    mq                  = (n2 > mq) ? n2 : mq;
-                    float *cell         = q_row0 + q_state * OK_Q_ACTIONS + q_action;
-                    const float old_q   = (q_action == 0) ? qc0 : ((q_action == 1) ? qc1 : qc2);
-                    const float new_q   = ok_q_learn(old_q, mq, reward);
-                    if (agent_ok && r == 0)
-                        __hip_atomic_store(cell, new_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    // the row carried into the next step: the current one with the learned value, or the next state's
-                    qc0 = (q_action == 0) ? new_q : qc0;
-                    qc1 = (q_action == 1) ? new_q : qc1;
-                    qc2 = (q_action == 2) ? new_q : qc2;
-                    if (!ag.crashed)
-                    {
-                        if (next_state != q_state)
-                        {
-                            qc0 = n0;
-                            qc1 = n1;
-                            qc2 = n2;
-                        }
-                        q_state = next_state;
-                    }
-                    else if (episode && agent_ok && r == 0)
+                    okQLearnStep(p, q_row0, agent_ok && r == 0, ag.crashed, next_state, nearest, n0, n1, n2, qs, qc0, qc1, qc2);
+                    if (ag.crashed && episode && agent_ok && r == 0)
                         p.q_next_state[okOpaque(a)] = next_state; // what every later step of this agent will see as its next state
                 }
             }
@@ -1374,9 +1406,9 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
         if (kPolicy == kPolicyQ && agent_ok && r == 0)
         {
             const int ae     = okOpaque(a);
-            p.q_state[ae]    = q_state;
-            p.q_action[ae]   = q_action;
-            p.q_prev_idx[ae] = q_prev;
+            p.q_state[ae]    = qs.state;
+            p.q_action[ae]   = qs.action;
+            p.q_prev_idx[ae] = qs.prev;
         }
 #if defined(OKENV_STAMPS)
         acc[4] = __builtin_amdgcn_s_memrealtime();
@@ -1454,6 +1486,293 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
         }
         res_seq = okNextPackedSeq(res_seq);
     }
+}
+
+// ---- the tail of an episode: few agents left, the whole machine free -----------------------------------------------------
+//
+// A rollout "until every agent has crashed" spends most of its steps on a handful of survivors (C3: under a tenth of the
+// population after 200 of 700-1800 steps), and a step of the cooperative kernel costs one wave's dependent chain -- about
+// 11 us for a 32-ray agent with the fused MLP -- however few agents there are.  This kernel shortens the chain instead of
+// sharing it: ONE agent per workgroup, every ray cut into kTailSplit = 8 parameter intervals from its origin on, one interval
+// per lane (32 rays: 256 lanes, four waves).  A lane walks 25 px; the eight lanes of a ray min-combine by DPP; the ray's first
+// lane does its epilogue.  The waves of the workgroup meet once per step: the rays' distances (the next policy's inputs) and
+// the waves' minima of the squared hit distances (the crash test) cross through LDS, double-buffered so that one barrier per
+// step is enough.  Every wave evaluates the policy for itself (same inputs, same order, same bits), so nothing else has to be
+// exchanged; with kR = 32 the lane's columns of both weight matrices stay in registers for the whole launch.
+// Exactness: ok_cast_poly_interval's contract (the min over a ray's intervals carries the bits of a single walk) -- what the
+// cooperative kernel's phase 2 and the direct dealing of small populations rely on as well.
+// LDS: [ image | 16 B unused | dist[2][64] | dist / 200 [2][64] (the MLP's inputs, divided once by the ray's lane) | min[2][8] |
+//        Q-learning: centre line + buckets ]
+constexpr int kTailSplit     = 8;
+constexpr int kTailLdsFloats = 4 * 64 + 2 * 8;
+
+template <int kPolicy, int kR>
+__global__ void __launch_bounds__(512) okStepTailKernel(const OkStepParams p, const uint32_t off_tail)
+{
+    static_assert(kPolicy != kPolicyNone, "policy kernels only");
+    extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
+    float    *s_dist     = reinterpret_cast<float *>(ok_lds + off_tail + 16);
+    float    *s_xs       = s_dist + 2 * 64;
+    float    *s_min      = s_xs + 2 * 64;
+    float    *lds_cx     = s_min + 2 * 8;
+    float    *lds_cy     = lds_cx + p.P;
+    uint16_t *lds_cstart = reinterpret_cast<uint16_t *>(lds_cy + p.P);
+    uint16_t *lds_cidx   = lds_cstart + (p.geom.nx * p.geom.ny + 1);
+    if (kPolicy == kPolicyQ)
+    {
+        for (int i = threadIdx.x; i < p.P; i += blockDim.x)
+        {
+            lds_cx[i] = p.cx[i];
+            lds_cy[i] = p.cy[i];
+        }
+        if (p.cl_start != nullptr)
+        {
+            for (int i = threadIdx.x; i <= p.geom.nx * p.geom.ny; i += blockDim.x)
+                lds_cstart[i] = p.cl_start[i];
+            for (int i = threadIdx.x; i < p.P; i += blockDim.x)
+                lds_cidx[i] = p.cl_idx[i];
+        }
+    }
+    const int  L      = static_cast<int>(threadIdx.x);
+    const int  lane   = L & 63, wave = L >> 6, n_waves = static_cast<int>(blockDim.x) >> 6;
+    const int  R      = kR > 0 ? kR : p.R;
+    const int  ray    = L / kTailSplit, part = L % kTailSplit;
+    const bool ray_ok = ray < R;
+    const bool out_ok = ray_ok && part == 0;
+    const bool listed = p.active != nullptr;
+    const int  a      = listed ? p.active[blockIdx.x] : static_cast<int>(blockIdx.x); // (the grid is exactly the agents to step)
+    const bool episode = p.settled != nullptr;
+    const long k       = static_cast<long>(a) * R + (ray_ok ? ray : 0);
+    const float ray_deg = p.ray_deg[ray_ok ? ray : 0];
+    OkAgentRegs ag      = okLoadAgent(p.st, a);
+    if (out_ok)
+    { // the previous observation: the first policy's inputs
+        const float d0 = p.st.dist[k];
+        s_dist[ray]    = d0;
+        s_xs[ray]      = d0 / 200.0F;
+    }
+    const OkPolyView view = okSetupView<kGridLds>(p, ok_lds); // ends with a barrier
+
+    OkQCarry qs{};
+    float    qc0 = 0.F, qc1 = 0.F, qc2 = 0.F;
+    float   *q_row0 = nullptr;
+    if (kPolicy == kPolicyQ)
+    {
+        qs.state         = p.q_state[a];
+        qs.action        = p.q_action[a];
+        qs.prev          = p.q_prev_idx[a];
+        q_row0           = p.q_table + static_cast<size_t>(a) * (OK_Q_STATES * OK_Q_ACTIONS);
+        const float *row = q_row0 + qs.state * OK_Q_ACTIONS;
+        qc0              = __hip_atomic_load(row + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        qc1              = __hip_atomic_load(row + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        qc2              = __hip_atomic_load(row + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the MLP's weights: hidden unit (lane & 31)'s column of w1, output (lane, clamped to 7)'s column of w2
+    const float *w1 = p.mlp_w + static_cast<size_t>(a) * OK_MLP_WEIGHTS(R);
+    const float *w2 = w1 + (R + 2) * OK_MLP_HID_PAD;
+    const int    ul = lane & (OK_MLP_HID_PAD - 1);
+    const int    kl = lane < OK_MLP_OUT_PAD ? lane : OK_MLP_OUT_PAD - 1;
+    constexpr int kCols = kR > 0 ? kR + 2 : 1;
+    float         wcol[kCols], vcol[OK_MLP_HID_PAD];
+    if (kPolicy == kPolicyMlp)
+    {
+        if (kR > 0)
+        {
+#pragma unroll
+            for (int j = 0; j < kCols; ++j)
+                wcol[j] = w1[j * OK_MLP_HID_PAD + ul];
+        }
+#pragma unroll
+        for (int i = 0; i < OK_MLP_HID_PAD; ++i)
+            vcol[i] = w2[i * OK_MLP_OUT_PAD + kl];
+    }
+
+    bool     settled = episode && p.settled[a] != 0;
+    uint32_t live_n  = 0U;
+#if defined(OKENV_STAMPS)
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast   = __builtin_amdgcn_s_memtime();
+    tacc[2]                    = __builtin_amdgcn_s_memrealtime();
+#define OK_TSTAMP(i)                                                                                                   \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                  \
+        tacc[i] += now_ - tlast;                                                                                       \
+        tlast = now_;                                                                                                  \
+    } while (0)
+#else
+#define OK_TSTAMP(i)
+#endif
+    for (int s = 0; s < p.n_steps; ++s)
+    {
+        if (episode && settled) // (the same in every lane of the workgroup: they all hold the one agent)
+            break;
+        const float *xs_in    = s_xs + (s & 1) * 64;         // written by the step before (or above)
+        float       *dist_out = s_dist + ((s & 1) ^ 1) * 64;
+        float       *xs_out   = s_xs + ((s & 1) ^ 1) * 64;
+        float       *min_out  = s_min + ((s & 1) ^ 1) * 8;
+        const bool   was_crashed = ag.crashed;
+        const bool   q_frozen    = kPolicy == kPolicyQ && episode && was_crashed;
+        if (kPolicy == kPolicyMlp)
+        { // GeneticAgent::updateAction: the same terms in the same order as okMlpAction, inputs read from LDS instead of shuffled
+            const float x0  = ag.speed / 100.0F;
+            const float x1  = ok_normalize_angle_deg(ag.rot) / 360.0F;
+            float       acc = 0.F;
+            if (kR > 0)
+            {
+                acc = acc + x0 * wcol[0];
+                acc = acc + x1 * wcol[1];
+#pragma unroll
+                for (int j = 0; j < (kR > 0 ? kR : 1); ++j)
+                    acc = acc + xs_in[j] * wcol[kR > 0 ? 2 + j : 0];
+            }
+            else
+            {
+                acc = acc + x0 * w1[0 * OK_MLP_HID_PAD + ul];
+                acc = acc + x1 * w1[1 * OK_MLP_HID_PAD + ul];
+                for (int j = 0; j < R; ++j)
+                    acc = acc + xs_in[j] * w1[(2 + j) * OK_MLP_HID_PAD + ul];
+            }
+            const float h = (acc > 0.F) ? acc : 0.F;
+            float       z = 0.F;
+#pragma unroll
+            for (int i = 0; i < OK_MLP_HID_PAD; ++i)
+                z = z + __shfl(h, i, 64) * vcol[i];
+            float zs[OK_MLP_OUT];
+#pragma unroll
+            for (int q = 0; q < OK_MLP_OUT; ++q)
+                zs[q] = __shfl(z, q, 64);
+            ok_ga_decode_action(zs, &ag.thr, &ag.steer);
+        }
+        if (kPolicy == kPolicyQ && !q_frozen)
+        {
+            qs.action = ok_q_choose_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s), p.q_epsilon,
+                                           qc0, qc1, qc2);
+            ok_q_action_values(qs.action, &ag.thr, &ag.steer);
+        }
+        OK_TSTAMP(0);
+        float sr, cr, rdx = 1.F, rdy = 0.F;
+        okAgentPreStep(p, ag, a, s, sr, cr, ray_deg, &rdy, &rdx);
+        const float ox    = ag.pos_x + p.sensor_offset * cr;
+        const float oy    = ag.pos_y + p.sensor_offset * sr;
+        const bool  casts = ray_ok && !ag.crashed;
+        OK_TSTAMP(1);
+        // the lane's interval of its ray; the intervals tile [0, inf) whatever dt rounds to (the last one is open-ended)
+        float found = OK_SENSOR_RANGE;
+        if (casts)
+        {
+            const float dt = OK_SENSOR_RANGE * okRcpApprox(static_cast<float>(kTailSplit));
+            const float ta = static_cast<float>(part) * dt;
+            const float tb = (part + 1 == kTailSplit) ? OKRC_INF : static_cast<float>(part + 1) * dt;
+            found          = ok_cast_poly_interval<false>(view, ox, oy, rdx, rdy, ta, tb, nullptr, nullptr, nullptr).min_t;
+        }
+        found = okGroupMin(found, kTailSplit);
+        OK_TSTAMP(3);
+        float min_d2 = OK_SENSOR_RANGE * OK_SENSOR_RANGE;
+        if (out_ok)
+        {
+            long ke = k;
+            asm volatile("" : "+v"(ke));
+            float hx, hy;
+            if (casts)
+            {
+                hx             = ox + found * rdx;
+                hy             = oy + found * rdy;
+                p.st.hit_x[ke] = hx;
+                p.st.hit_y[ke] = hy;
+            }
+            else
+            { // stale world hit point of a crashed agent
+                hx = p.st.hit_x[ke];
+                hy = p.st.hit_y[ke];
+            }
+            float d;
+            min_d2        = okRayEpilogue(p.st, ke, hx, hy, ox, oy, sr, cr, d);
+            min_d2        = (min_d2 < OK_SENSOR_RANGE * OK_SENSOR_RANGE) ? min_d2 : OK_SENSOR_RANGE * OK_SENSOR_RANGE;
+            dist_out[ray] = d;
+            if (kPolicy == kPolicyMlp)
+                xs_out[ray] = d / 200.0F; // Network::infer's input (Network.hpp:131), formed once here instead of by every lane of every wave
+        }
+        min_d2 = okGroupMin(min_d2, 64);
+        if (lane == 0)
+            min_out[wave] = min_d2;
+        OK_TSTAMP(5);
+        __syncthreads(); // the one meeting of the step: distances and minima of all waves are in LDS
+        OK_TSTAMP(6);
+        for (int w = 0; w < n_waves; ++w)
+        {
+            const float o = min_out[w];
+            min_d2        = (o < min_d2) ? o : min_d2;
+        }
+        if (min_d2 < OK_CRASH_DIST2)
+            ag.crashed = true;
+        if (kPolicy == kPolicyQ)
+        { // q_racer_sim.cpp:171-182
+            int next_state = 0, mult = 1;
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+            {
+                next_state += ok_q_bin(dist_out[p.q_ray[i]]) * mult;
+                mult *= 3;
+            }
+            float n0 = 0.F, n1 = 0.F, n2 = 0.F;
+            if (!q_frozen)
+            {
+                const float *nrow = q_row0 + next_state * OK_Q_ACTIONS;
+                n0                = __hip_atomic_load(nrow + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                n1                = __hip_atomic_load(nrow + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                n2                = __hip_atomic_load(nrow + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const int nearest = okNearestBucketed(p, lds_cx, lds_cy, lds_cstart, lds_cidx, ag.pos_x, ag.pos_y, lane, 64);
+            if (!q_frozen)
+            {
+                okQLearnStep(p, q_row0, L == 0, ag.crashed, next_state, nearest, n0, n1, n2, qs, qc0, qc1, qc2);
+                if (ag.crashed && episode && L == 0)
+                    p.q_next_state[okOpaque(a)] = next_state;
+            }
+        }
+        OK_TSTAMP(7);
+        if (episode)
+        {
+            if (was_crashed)
+                settled = true;
+            else
+            {
+                ++live_n;
+                if (ag.crashed && L == 0)
+                {
+                    const int ae      = okOpaque(a);
+                    p.crash_step[ae]  = p.ep_step0 + static_cast<uint32_t>(s) + 1U;
+                    p.crash_thr[ae]   = ag.thr;
+                    p.crash_steer[ae] = ag.steer;
+                }
+            }
+        }
+    }
+#if defined(OKENV_STAMPS)
+    tacc[4] = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0 && p.stamps != nullptr)
+        for (int i = 0; i < 8; ++i)
+            p.stamps[(static_cast<long>(blockIdx.x) * n_waves + wave) * kStampWords + i] = tacc[i];
+#endif
+    if (L == 0)
+    {
+        okStoreAgent(p.st, a, ag);
+        if (kPolicy == kPolicyQ)
+        {
+            const int ae     = okOpaque(a);
+            p.q_state[ae]    = qs.state;
+            p.q_action[ae]   = qs.action;
+            p.q_prev_idx[ae] = qs.prev;
+        }
+        if (episode)
+        {
+            p.settled[okOpaque(a)] = settled ? 1 : 0;
+            if (live_n != 0U)
+                atomicAdd(p.live, static_cast<unsigned long long>(live_n));
+        }
+    }
+    okFinishLaunch(p);
 }
 
 // ---- small service kernels ------------------------------------------------------------------------------

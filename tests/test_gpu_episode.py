@@ -75,6 +75,27 @@ def test_ga_episode_equals_reference_loop(gpu, oracle, track_name, N, R, spl):
     dev.close()
 
 
+@pytest.mark.parametrize("tail", ["0", "40"])
+def test_ga_episode_lists_on_the_cooperative_kernel(gpu, oracle, monkeypatch, tail):
+    """Populations this small are stepped by the tail kernel (one agent per workgroup) from the first compaction on; with it
+    switched off (OKENV_TAIL_MAX_AGENTS=0) the lists go through the cooperative kernel, with a limit of 40 agents through the
+    cooperative kernel first and the tail kernel once the list is that short -- three ways to the same bits."""
+    monkeypatch.setenv("OKENV_TAIL_MAX_AGENTS", tail)
+    t, dev, orc, ga = make_ga(gpu, oracle, "Monza", 96, 32)
+    start = (float(t.x[3]), float(t.y[3]), float(t.heading[0]))
+    for generation in range(2):
+        dev.reset_all(*start)
+        ga.reset_all(*start)
+        dev.step(1)
+        orc.step(1)
+        want = oracle_ga_loop(orc, ga, 1500)
+        steps, live, listed = device_ga_loop(dev, 25, 1500)
+        assert (steps, live) == want
+        assert_same_state(dev.snapshot(), orc.snapshot(), "generation %d" % generation)
+        assert np.array_equal(dev.ga_select_mate(5, generation), ga.select_mate(5, generation))
+    dev.close()
+
+
 def test_ga_episode_with_step_cap_and_agents_crashed_before_it_begins(gpu, oracle):
     """the caller's own cap ends the loop with agents alive: every step taken counts and nothing is put back; agents that are
     crashed when the episode begins are asked for an action once, like everybody else in the reference's loop"""
@@ -177,6 +198,15 @@ def test_q_episode_equals_reference_loop(gpu, oracle, track_name, N, R, spl):
 
 
 def test_q_episode_short_list_gets_wider_lane_groups(gpu, oracle, monkeypatch):
+    monkeypatch.setenv("OKENV_TAIL_MAX_AGENTS", "0")   # (the cooperative kernel's treatment of short lists; the tail kernel is the default)
+    _q_short_list(gpu, oracle, monkeypatch)
+
+
+def test_q_episode_short_list_on_the_tail_kernel(gpu, oracle, monkeypatch):
+    _q_short_list(gpu, oracle, monkeypatch)
+
+
+def _q_short_list(gpu, oracle, monkeypatch):
     """a population created with narrow lane groups (as the 16384 agents of BASELINE config 5 are: four agents to a wave) whose
     list has become short is launched with wider groups and no phase 1; nothing but the time may change"""
     monkeypatch.setenv("OKENV_LANES_PER_AGENT", "16")
