@@ -38,21 +38,24 @@ try:
     lines.append(json.dumps(bench))
 except Exception as e:
     lines.append("bench line unreadable: %s" % e)
-# counters: sums over ALL dispatches of the policy step kernel in the run (launches differ in length and in listed agents)
+# the fused policy step kernels: the cooperative kernel (full population, long lists) and the tail kernel (short lists)
+def is_policy_kernel(name):
+    return any(k in name for k in ("okStepCoopKernel<1", "okStepCoopKernel<2", "okStepTailKernel<1", "okStepTailKernel<2"))
+# counters: sums over ALL dispatches of the policy step kernels in the run (launches differ in length and in listed agents)
 tot = collections.defaultdict(float); n = collections.defaultdict(int)
 for f in glob.glob(out + "/pmc*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "okStepCoopKernel<1" in r["Kernel_Name"] or "okStepCoopKernel<2" in r["Kernel_Name"] or "OkPolicyKind)1" in r["Kernel_Name"] or "OkPolicyKind)2" in r["Kernel_Name"]:
+        if is_policy_kernel(r["Kernel_Name"]):
             tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
-lines.append("== PMC, fused policy step kernel, SUM over the run's dispatches (warm-up generation / episode included) ==")
+lines.append("== PMC, fused policy step kernels (cooperative + tail), SUM over the run's dispatches (warm-up generation / episode included) ==")
 for k in sorted(tot):
     lines.append("%-26s %20.0f   (%d dispatches)" % (k, tot[k], n[k]))
 live = float(bench["rank0_live_agent_steps_with_warmup"]) if bench else None
 kern_ns = None
 for f in glob.glob(out + "/stats/*/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
-        if "okStepCoopKernel<1" in r["Name"] or "okStepCoopKernel<2" in r["Name"]:
-            kern_ns = float(r["TotalDurationNs"])
+        if is_policy_kernel(r["Name"]):
+            kern_ns = (kern_ns or 0.0) + float(r["TotalDurationNs"])
 if live and kern_ns:
     lines.append("the run (warm-up included): %.4e live agent-steps, policy step kernel busy %.3f ms -> %.3e live agent-steps/s kernel-only" % (live, kern_ns * 1e-6, live / (kern_ns * 1e-9)))
 if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
