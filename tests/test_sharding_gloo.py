@@ -117,8 +117,19 @@ GA_WORKER = textwrap.dedent('''
         def policy_mlp_create(self, hidden, seed, agent_base): self.ga = O.OracleGA(self.env, hidden, seed, agent_base)
         def reset_all(self, x, y, rot): self.ga.reset_all(x, y, rot)
         def step(self, n): self.env.step(n)
-        def rollout_policy(self, n): self.ga.rollout_policy(n)
         def alive_count(self): return self.ga.alive_count()
+        # episodes (include/okenv.h): the reference's loop, which leaves with the step in which the last agent crashes
+        def episode_begin(self): self._taken, self._T, self._live = 0, 0, 0
+        def rollout_policy(self, n):
+            for _ in range(n):
+                alive = self.ga.alive_count()
+                if alive > 0 or self._taken == 0:   # (at least one iteration is always taken)
+                    self._live += alive
+                    self.ga.rollout_policy(1)
+                    self._T = self._taken + 1
+                self._taken += 1
+        def episode_compact(self): return self.ga.alive_count(), self.ga.alive_count()
+        def episode_end(self): return self._T, self._live
         def ga_scores(self): return self.ga.scores()
         def ga_select_mate(self, seed, generation, agent_base): return self.ga.select_mate(seed, generation, agent_base)
         def sync(self): pass
@@ -165,10 +176,9 @@ def test_two_rank_generation_loop_all_gathers_fitness(oracle, tmp_path):
             ga.reset_all(*start)
             env1.step(1)
             steps = 1
-            while steps < 260:
-                n = min(65, 260 - steps)
-                ga.rollout_policy(n)
-                steps += n
+            while steps < 260:  # the reference's loop, one iteration at a time
+                ga.rollout_policy(1)
+                steps += 1
                 if ga.alive_count() == 0:
                     break
             scores[(rank, g)] = ga.scores()
