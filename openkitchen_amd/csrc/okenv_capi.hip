@@ -541,7 +541,13 @@ int stepResident(okenv *h, const okenv_agent_record *in, volatile uint32_t *slot
         // (auto-reset makes a handle ineligible) and writes only the exchange buffers and the per-ray arrays, which the redo
         // overwrites with the same values.  Anything added to the resident form that accumulates device state breaks this.
         if (waited_us > (just_started ? 2.0e6 : 2.5 * kResidentGapUs))
+        { // ... and only a kernel that has really left is given up on: one that is still on its stream is merely slow (it polls
+          // its slot every few hundred nanoseconds, so it has the step) and will answer -- up to a bound, so that a hung device
+          // ends in the launch path's error and not in an endless wait
+            if (!just_started && waited_us < 20000.0 && hipStreamQuery(h->resident_stream) == hipErrorNotReady)
+                continue;
             break;
+        }
         if (just_started && waited_us > 1000.0 && hipStreamQuery(h->resident_stream) != hipErrorNotReady)
             break; // its stream has drained (or failed): nobody is going to answer
     }
