@@ -1,7 +1,7 @@
 """Randomised differential test of EPISODES (okenv_episode_begin / _compact / _end: work follows the live agents, the reference
 loop's own length comes back) against the reference's loop replayed on the CPU oracle one Environment::step at a time (run on
 the GPU box).  Random track, population, fan, hidden width / Q-learning, launch lengths, step caps, agents crashed before the
-episode, tail-kernel limit, lane-group width, phase-1 range.  usage: python tools/fuzz_episodes.py [seconds] [seed]"""
+episode, tail-kernel limit, lane-group width, phase-1 range.  usage: python tests/tools/fuzz_episodes.py [seconds] [seed]"""
 import os
 import sys
 import time

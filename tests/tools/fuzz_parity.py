@@ -1,7 +1,7 @@
 """Randomised differential test of the device path against the CPU oracle (run on the GPU box):
 random track, population, fan (including non-monotone and duplicate angles), movement mode, sensor offset, cell size,
 lane-group width and phase-1 range, with the bench driver loop or host actions + auto-reset.  Every state field is
-compared bit for bit.  usage: python tools/fuzz_parity.py [seconds] [seed]"""
+compared bit for bit.  usage: python tests/tools/fuzz_parity.py [seconds] [seed]"""
 import os
 import sys
 import time

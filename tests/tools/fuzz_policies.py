@@ -1,5 +1,5 @@
 """Randomised differential test of the fused caller kernels (EvolutionaryRacer MLP policy + select/mate, tabular
-Q-learning) against the CPU oracle (run on the GPU box).  usage: python tools/fuzz_policies.py [seconds] [seed]"""
+Q-learning) against the CPU oracle (run on the GPU box).  usage: python tests/tools/fuzz_policies.py [seconds] [seed]"""
 import os
 import sys
 import time

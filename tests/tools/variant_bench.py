@@ -1,13 +1,13 @@
 """Development aid: time library variants (tools/build_variant.sh) on the C2 workload and check each against the oracle.
 
-usage (GPU box): python tools/variant_bench.py v0 v1 "v1:OKENV_PHASE1_RANGE=32" "v1:cell=16" ...
+usage (GPU box): python tests/tools/variant_bench.py v0 v1 "v1:OKENV_PHASE1_RANGE=32" "v1:cell=16" ...
 Each variant runs in its own process (the library path is fixed at import).  bench.py stays the judged harness.
 """
 import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 CHILD = r'''
 import os, sys, time

@@ -1,6 +1,6 @@
-"""Development aid: lock-step trip counts of the cooperative raycast (tools/wave_model.cpp) on bench-recipe poses.
+"""Development aid: lock-step trip counts of the cooperative raycast (tests/tools/wave_model.cpp) on bench-recipe poses.
 
-usage: python tools/wave_model.py [track] [agents] [rays]
+usage: python tests/tools/wave_model.py [track] [agents] [rays]
 Poses come from the CPU oracle's rollout of the bench recipe (test infrastructure used as a pose generator only).
 """
 import ctypes as C
@@ -10,7 +10,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _oracle as O  # noqa: E402
 
@@ -20,7 +20,7 @@ SO = os.path.join(ROOT, "tools", "_build", "libwavemodel.so")
 def build():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
-                    "-I", os.path.join(ROOT, "openkitchen_amd", "csrc"), "-o", SO, os.path.join(ROOT, "tools", "wave_model.cpp")], check=True)
+                    "-I", os.path.join(ROOT, "openkitchen_amd", "csrc"), "-o", SO, os.path.join(ROOT, "tests", "tools", "wave_model.cpp")], check=True)
     L = C.CDLL(SO)
     f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
     L.wavemodel_run.argtypes = [f32p, C.c_int, C.c_float, f32p, f32p, f32p, C.c_int, f32p, C.c_int, C.c_float, C.c_int, C.c_int,
