@@ -401,6 +401,18 @@ OK_HD int ok_q_choose_action(uint32_t seed, uint32_t agent, uint32_t step, float
     return ok_q_argmax3(q0, q1, q2);
 }
 
+/* The part of that draw that does not depend on the Q values: -1 = exploit (take the argmax), else the random action.  For
+ * callers that make many steps' draws at once (okQSettleKernel); ok_q_choose_action == (d < 0 ? argmax3 : d). */
+OK_HD int ok_q_draw_action(uint32_t seed, uint32_t agent, uint32_t step, float epsilon)
+{
+    const ok_u32x4 r = ok_philox4x32(agent, step, 4u, 0u, seed, 0x6F6B656Eu);
+    if (ok_u01(r.v[0]) < epsilon) {
+        const int a = (int)(ok_u01(r.v[1]) * 3.0f);
+        return a > 2 ? 2 : a;
+    }
+    return -1;
+}
+
 /* kActionMap (QAgent.hpp:40-42): 0 -> (60, 0), 1 -> (30, +5), 2 -> (30, -5) */
 OK_HD void ok_q_action_values(int action, float *throttle, float *steer)
 {

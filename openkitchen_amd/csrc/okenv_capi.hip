@@ -1900,7 +1900,8 @@ extern "C"
             hipLaunchKernelGGL(okEpisodeFixupKernel, dim3(blocks), dim3(256), 0, h->stream, h->st, h->d_crash_step, h->d_crash_thr, h->d_crash_steer,
                                h->d_ep_out, h->N);
         else if (h->ep_kind == kPolicyQ)
-            hipLaunchKernelGGL(okQSettleKernel, dim3(blocks), dim3(256), 0, h->stream, h->st, h->d_q_table, h->d_q_state, h->d_q_action,
+            hipLaunchKernelGGL(okQSettleKernel, dim3(static_cast<unsigned>((static_cast<long>(h->N) * kSettleLanes + 255) / 256)), dim3(256), 0,
+                               h->stream, h->st, h->d_q_table, h->d_q_state, h->d_q_action,
                                h->d_q_next_state, h->d_crash_step, h->d_ep_out, h->N, h->ep_q_seed, h->ep_q_agent_base, h->ep_q_step_base,
                                h->ep_q_epsilon);
         OK_HIP(h, hipGetLastError());

@@ -2256,51 +2256,52 @@ __global__ void okEpisodeBeginKernel(const uint8_t *crashed, uint8_t *settled, u
     crash_step[a] = crashed[a] != 0 ? 0U : 0xFFFFFFFFU;
 }
 
-// counts[0] = agents alive, counts[1] = agents listed.  The list of the agents that are not settled yet, ascending; one workgroup
-// (N <= 65535 agents: at most 64 passes of 1024).
+// counts[0] = agents alive, counts[1] = agents listed.  The list of the agents that are not settled yet, ascending.  One
+// workgroup: every thread takes a contiguous run of ceil(N / 1024) agents, the runs' counts are scanned once (wave ballots
+// are no help with runs; a shared-memory scan over the 16 waves' totals is), then every thread writes its run's entries.
 __global__ void __launch_bounds__(1024) okEpisodeCompactKernel(const uint8_t *settled, const uint8_t *crashed, int N, int32_t *active, int32_t *counts)
 {
-    __shared__ int wave_sum[16];
-    __shared__ int base_s, alive_s;
-    if (threadIdx.x == 0)
+    __shared__ int wave_keep[16], wave_live[16];
+    const int t = static_cast<int>(threadIdx.x), lane = t & 63, wave = t >> 6;
+    const int per = (N + 1023) / 1024;
+    const int lo = t * per, hi = (lo + per < N) ? lo + per : N;
+    int keep = 0, live = 0;
+    for (int i = lo; i < hi; ++i)
     {
-        base_s  = 0;
-        alive_s = 0;
+        keep += settled[i] == 0 ? 1 : 0;
+        live += crashed[i] == 0 ? 1 : 0;
     }
+    // inclusive scan of `keep` inside the wave (and the wave's sum of `live`)
+    int scan = keep;
+    for (int off = 1; off < 64; off <<= 1)
+    {
+        const int o = __shfl_up(scan, off, 64);
+        if (lane >= off)
+            scan += o;
+    }
+    int live_w = live;
+    for (int off = 32; off > 0; off >>= 1)
+        live_w += __shfl_xor(live_w, off, 64);
+    if (lane == 63)
+        wave_keep[wave] = scan;
+    if (lane == 0)
+        wave_live[wave] = live_w;
     __syncthreads();
-    const int lane = static_cast<int>(threadIdx.x) & 63, wave = static_cast<int>(threadIdx.x) >> 6;
-    for (int i0 = 0; i0 < N; i0 += 1024)
+    int before = scan - keep, total = 0, alive = 0;
+    for (int w = 0; w < 16; ++w)
     {
-        const int  i    = i0 + static_cast<int>(threadIdx.x);
-        const bool keep = i < N && settled[i] == 0;
-        const bool live = i < N && crashed[i] == 0;
-        const unsigned long long mk = __ballot(keep), ml = __ballot(live);
-        if (lane == 0)
-        {
-            wave_sum[wave] = __popcll(mk);
-            if (ml != 0ULL)
-                atomicAdd(&alive_s, __popcll(ml));
-        }
-        __syncthreads();
-        int before = base_s;
-        for (int w = 0; w < wave; ++w)
-            before += wave_sum[w];
-        if (keep)
-            active[before + __popcll(mk & ((1ULL << lane) - 1ULL))] = i;
-        __syncthreads();
-        if (threadIdx.x == 0)
-        {
-            int tot = 0;
-            for (int w = 0; w < 16; ++w)
-                tot += wave_sum[w];
-            base_s += tot;
-        }
-        __syncthreads();
+        if (w < wave)
+            before += wave_keep[w];
+        total += wave_keep[w];
+        alive += wave_live[w];
     }
-    if (threadIdx.x == 0)
+    for (int i = lo; i < hi; ++i)
+        if (settled[i] == 0)
+            active[before++] = i;
+    if (t == 0)
     {
-        counts[0] = alive_s;
-        counts[1] = base_s;
+        counts[0] = alive;
+        counts[1] = total;
     }
 }
 
@@ -2352,45 +2353,62 @@ __global__ void okEpisodeFixupKernel(OkDeviceState st, const uint32_t *crash_ste
 // Q-learning: what the reference's loop does with an agent after its crash, up to and including step T (q_racer_sim.cpp:158-182):
 // every step an epsilon-greedy action from the row of its (no longer changing) state, then learn(state, action, -200, next state)
 // with the next state it has seen ever since the crash step.  Only the agent's own table is involved, so the steps c + 1 .. T
-// are replayed here, one thread per agent, once T is known; the step kernel leaves crashed agents' tables alone inside an episode.
+// are replayed here once T is known; the step kernel leaves crashed agents' tables alone inside an episode.
+// kSettleLanes lanes per agent: the Philox draws of sixteen steps are made side by side (they do not depend on the table), then
+// every lane of the group takes the sixteen learn() steps in order from the shuffled draws (the same values in each lane).
+constexpr int kSettleLanes = 16;
+
 __global__ void okQSettleKernel(OkDeviceState st, float *q_table, const int32_t *q_state, int32_t *q_action, const int32_t *q_next_state,
                                 const uint32_t *crash_step, const uint32_t *T_ptr, int N, uint32_t seed, uint32_t agent_base,
                                 uint32_t step_base, float epsilon)
 {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= N || st.crashed[a] == 0)
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int a   = gid / kSettleLanes, l = gid % kSettleLanes;
+    if (a >= N || st.crashed[a] == 0) // (the same for all lanes of a group)
         return;
     const uint32_t T = T_ptr[0], c = crash_step[a];
     if (c >= T)
         return;
-    float *table = q_table + static_cast<size_t>(a) * (OK_Q_STATES * OK_Q_ACTIONS);
-    const int sc = q_state[a];
+    float    *table = q_table + static_cast<size_t>(a) * (OK_Q_STATES * OK_Q_ACTIONS);
+    const int sc    = q_state[a];
     // an agent that was crashed when the episode began (c == 0) sees the state of the initial observation as its next state
-    const int sn = c == 0U ? sc : q_next_state[a];
-    float cur[3], nxt[3];
-    for (int k = 0; k < 3; ++k)
-    {
-        cur[k] = table[sc * OK_Q_ACTIONS + k];
-        nxt[k] = table[sn * OK_Q_ACTIONS + k];
-    }
+    const int  sn   = c == 0U ? sc : q_next_state[a];
+    const bool same = sn == sc;
+    float c0 = table[sc * OK_Q_ACTIONS + 0], c1 = table[sc * OK_Q_ACTIONS + 1], c2 = table[sc * OK_Q_ACTIONS + 2];
+    const float n0 = table[sn * OK_Q_ACTIONS + 0], n1 = table[sn * OK_Q_ACTIONS + 1], n2 = table[sn * OK_Q_ACTIONS + 2];
     int action = q_action[a];
-    for (uint32_t i = c + 1U; i <= T; ++i)
+    for (uint32_t i0 = c + 1U; i0 <= T; i0 += kSettleLanes)
     { // episode step i is global step step_base + i - 1 of the Philox stream
-        action          = ok_q_choose_action(seed, agent_base + static_cast<uint32_t>(a), step_base + i - 1U, epsilon, cur[0], cur[1], cur[2]);
-        const float *nx = (sn == sc) ? cur : nxt;
-        float        mq = nx[0];
-        mq              = (nx[1] > mq) ? nx[1] : mq;
-        mq              = (nx[2] > mq) ? nx[2] : mq;
-        const float old_q = (action == 0) ? cur[0] : ((action == 1) ? cur[1] : cur[2]);
-        const float new_q = ok_q_learn(old_q, mq, -200.0F);
-        cur[0]            = (action == 0) ? new_q : cur[0];
-        cur[1]            = (action == 1) ? new_q : cur[1];
-        cur[2]            = (action == 2) ? new_q : cur[2];
+        const uint32_t i    = i0 + static_cast<uint32_t>(l);
+        const int      draw = i <= T ? ok_q_draw_action(seed, agent_base + static_cast<uint32_t>(a), step_base + i - 1U, epsilon) : -1;
+        const int      n    = (T - i0 + 1U) < static_cast<uint32_t>(kSettleLanes) ? static_cast<int>(T - i0 + 1U) : kSettleLanes;
+        // the sixteen draws, two bits each (3 = exploit), gathered into one word that every lane of the group holds
+        uint32_t packed = static_cast<uint32_t>(draw < 0 ? 3 : draw) << (2 * l);
+        for (int off = 1; off < kSettleLanes; off <<= 1)
+            packed |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(packed), off, kSettleLanes));
+        for (int k = 0; k < n; ++k)
+        {
+            const int d = static_cast<int>((packed >> (2 * k)) & 3U);
+            action      = d == 3 ? ok_q_argmax3(c0, c1, c2) : d;
+            float mq    = same ? c0 : n0;
+            const float m1 = same ? c1 : n1, m2 = same ? c2 : n2;
+            mq             = (m1 > mq) ? m1 : mq;
+            mq             = (m2 > mq) ? m2 : mq;
+            const float old_q = (action == 0) ? c0 : ((action == 1) ? c1 : c2);
+            const float new_q = ok_q_learn(old_q, mq, -200.0F);
+            c0                = (action == 0) ? new_q : c0;
+            c1                = (action == 1) ? new_q : c1;
+            c2                = (action == 2) ? new_q : c2;
+        }
     }
-    for (int k = 0; k < 3; ++k)
-        table[sc * OK_Q_ACTIONS + k] = cur[k];
-    q_action[a] = action;
-    ok_q_action_values(action, &st.thr[a], &st.steer[a]);
+    if (l == 0)
+    {
+        table[sc * OK_Q_ACTIONS + 0] = c0;
+        table[sc * OK_Q_ACTIONS + 1] = c1;
+        table[sc * OK_Q_ACTIONS + 2] = c2;
+        q_action[a]                  = action;
+        ok_q_action_values(action, &st.thr[a], &st.steer[a]);
+    }
 }
 
 // ---- RLRacers/Q_Learning service kernels ----------------------------------------------------------------------
