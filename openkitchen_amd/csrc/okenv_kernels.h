@@ -1287,8 +1287,9 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                 const int  j      = lane - q * m;
                 const bool has    = q < n;
                 const int  owner  = __shfl(owner_of_rank, has ? q : 0, 64);
-                const float tox   = __shfl(ox, owner, 64);
-                const float toy   = __shfl(oy, owner, 64);
+                // (one agent per wave: every lane already holds the one origin)
+                const float tox   = kG == 64 ? ox : __shfl(ox, owner, 64);
+                const float toy   = kG == 64 ? oy : __shfl(oy, owner, 64);
                 const float tdx   = __shfl(rdx, owner, 64);
                 const float tdy   = __shfl(rdy, owner, 64);
                 const float t0    = __shfl(t_reached, owner, 64);
