@@ -303,8 +303,9 @@ OKENV_API int okenv_alive_count(okenv_t h, int32_t *out);
  *     Q table and the step count exactly as the reference's loop leaves them after step T, whatever the launches' lengths.
  *     Q-learning's per-step update of CRASHED agents (epsilon-greedy draw + learn with reward -200, q_racer_sim.cpp:158-182)
  *     is replayed per agent for its steps crash+1 .. T at that point.
- * Typical loop:   okenv_episode_begin(h);
- *                 do { okenv_rollout_policy(h, n); okenv_episode_compact(h, &alive, NULL); } while (alive > 0 && more steps allowed);
+ * Typical loop:   okenv_episode_begin(h);  okenv_episode_tail_limit(h, &tail);  listed = N;
+ *                 do { okenv_rollout_policy(h, listed <= tail ? all the steps still allowed : n);
+ *                      okenv_episode_compact(h, &alive, &listed); } while (alive > 0 && more steps allowed);
  *                 okenv_episode_end(h, &steps, &live);
  * Needs auto-reset off.  Any call that changes agent state from outside (set/upload/reset/step without a policy) ends the
  * episode without the end-of-episode corrections. */
@@ -312,6 +313,10 @@ OKENV_API int okenv_episode_begin(okenv_t h);
 /* Rebuilds the list of agents the next rollouts step; *alive_out = agents with crashed_ == false (the loop's all_done test),
  * *listed_out = agents still stepped (alive ones + those that crashed in the last step taken).  Either may be NULL. */
 OKENV_API int okenv_episode_compact(okenv_t h, int32_t *alive_out, int32_t *listed_out);
+/* Longest list (okenv_episode_compact's *listed_out) that is stepped one agent per workgroup on this handle (0: never).  Such
+ * a workgroup leaves as soon as its agent is done, so from there on the caller may ask for ALL the steps it still allows in
+ * one rollout call: the launch ends with the step in which the last agent crashes, and no launch boundary is paid any more. */
+OKENV_API int okenv_episode_tail_limit(okenv_t h, int32_t *out);
 /* *steps_out = T (steps of the reference's loop; all steps taken if somebody is still alive), *live_agent_steps_out = sum over
  * the steps of the agents that entered the step alive.  Either may be NULL. */
 OKENV_API int okenv_episode_end(okenv_t h, int32_t *steps_out, uint64_t *live_agent_steps_out);

@@ -46,7 +46,7 @@ SYMBOLS = [
     "okenv_set_step_count", "okenv_field_device_ptr", "okenv_tracker_create", "okenv_tracker_begin",
     "okenv_tracker_update", "okenv_step_packed",
     "okenv_controller_create", "okenv_controller_num_params", "okenv_controller_set_params", "okenv_controller_act",
-    "okenv_episode_begin", "okenv_episode_compact", "okenv_episode_end", "okenv_work_stats",
+    "okenv_episode_begin", "okenv_episode_compact", "okenv_episode_end", "okenv_episode_tail_limit", "okenv_work_stats",
 ]
 
 
@@ -162,6 +162,7 @@ def load(build_if_missing=True):
     L.okenv_episode_begin.argtypes = [vp]
     L.okenv_episode_compact.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.okenv_episode_end.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_uint64)]
+    L.okenv_episode_tail_limit.argtypes = [vp, C.POINTER(i32)]
     _lib = L
     return L
 

@@ -116,14 +116,16 @@ int main(int argc, char **argv)
         // (include/okenv.h): only the agents that can still change are stepped, and `iteration` is the reference's own count --
         // its loop leaves with the step in which the last agent crashes, wherever the launches end
         CHECK(okenv_episode_begin(env));
+        int32_t tail = 0;
+        CHECK(okenv_episode_tail_limit(env, &tail));
         int     iteration = 1;
-        int32_t alive     = N;
+        int32_t alive = N, listed = N;
         while (alive > 0 && iteration < opt.max_steps)
-        {
-            const int n = std::min(opt.steps_per_launch, opt.max_steps - iteration);
+        { // a short list is stepped one agent per workgroup, each leaving with its agent: one launch for all that is left
+            const int n = listed <= tail ? opt.max_steps - iteration : std::min(opt.steps_per_launch, opt.max_steps - iteration);
             CHECK(okenv_rollout_policy(env, n));
             iteration += n;
-            CHECK(okenv_episode_compact(env, &alive, nullptr));
+            CHECK(okenv_episode_compact(env, &alive, &listed));
         }
         int32_t loop_steps = 0;
         CHECK(okenv_episode_end(env, &loop_steps, nullptr));

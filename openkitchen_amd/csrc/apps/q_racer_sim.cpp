@@ -118,14 +118,16 @@ int main(int argc, char **argv)
         // okenv_episode_end returns the loop's own length and leaves agents and tables as the loop does -- a crashed agent's
         // per-step draw and -200 update (:158-182) are made there, up to that last step and not beyond.
         CHECK(okenv_episode_begin(env));
+        int32_t tail = 0;
+        CHECK(okenv_episode_tail_limit(env, &tail));
         int     steps = 0;
-        int32_t alive = N;
+        int32_t alive = N, listed = N;
         while (alive > 0 && steps < opt.max_steps)
-        {
-            const int n = std::min(opt.steps_per_launch, opt.max_steps - steps);
+        { // a short list is stepped one agent per workgroup, each leaving with its agent: one launch for all that is left
+            const int n = listed <= tail ? opt.max_steps - steps : std::min(opt.steps_per_launch, opt.max_steps - steps);
             CHECK(okenv_rollout_q(env, n, epsilon, opt.seed, 0, steps_total + static_cast<uint32_t>(steps)));
             steps += n;
-            CHECK(okenv_episode_compact(env, &alive, nullptr));
+            CHECK(okenv_episode_compact(env, &alive, &listed));
         }
         int32_t loop_steps = 0;
         CHECK(okenv_episode_end(env, &loop_steps, nullptr));

@@ -595,6 +595,8 @@ int waitPackedDone(okenv *h, const volatile uint32_t *word, const uint32_t seq)
     }
 }
 
+long tailLimit(const okenv *h, bool q_launch);
+
 int launchStep(okenv *h, OkStepParams p) // (by value: the diagnostic build adds its stamp buffer)
 {
     OK_HIP(h, hipSetDevice(h->device));
@@ -646,16 +648,11 @@ int launchStep(okenv *h, OkStepParams p) // (by value: the diagnostic build adds
     // (okStepTailKernel).  Two such workgroups fit a CU's LDS; beyond about two rounds of them the cooperative kernel's shared
     // waves win again.
     const bool q_launch = p.action_source == kActionsQLearning;
-    if (p.active != nullptr && h->grid_mode == kGridLds && h->coop && (policy == kPolicyMlp || q_launch) && p.n_active > 0 &&
-        h->tail_max_agents != 0)
+    if (p.active != nullptr && (policy == kPolicyMlp || q_launch) && p.n_active > 0)
     {
         const unsigned lanes = static_cast<unsigned>(((h->R * kTailSplit + 63) / 64) * 64);
         const size_t   lds   = h->image_bytes + 16U + sizeof(float) * kTailLdsFloats + (q_launch ? qLdsBytes(h) : 0U);
-        // one round of workgroups: as many per CU as the LDS holds, 256 CUs (measured, 32-ray MLP agents: 8.5 us per step up to
-        // 256 agents, 10.3 at 512 with two per CU, against 11.2-11.8 for the cooperative kernel; a second round loses: 17 us)
-        const long fit       = lds <= kLdsBudget ? static_cast<long>(kLdsBudget / lds) * 256L : 0L;
-        const long max_tail  = h->tail_max_agents > 0 ? std::min<long>(h->tail_max_agents, fit) : fit;
-        if (lanes <= 512U && p.n_active <= max_tail)
+        if (p.n_active <= tailLimit(h, q_launch))
         {
             p.G = h->G; // (unused by the tail kernel; undo the widening above)
             const dim3     tgrid(static_cast<unsigned>(p.n_active)), tblock(lanes);
@@ -734,6 +731,21 @@ int launchStep(okenv *h, OkStepParams p) // (by value: the diagnostic build adds
 #undef OK_LAUNCH_GENERIC
     OK_HIP(h, hipGetLastError());
     return endTiming(h, ev);
+}
+
+// Longest episode list the tail kernel (okStepTailKernel) takes on this handle: one round of workgroups -- as many per CU as
+// the LDS holds, 256 CUs (measured, 32-ray MLP agents: 8.1 us per step up to 256 agents, 9.2 at 512 with two per CU, against
+// 11.2-11.8 for the cooperative kernel; a second round loses: 17 us) -- or OKENV_TAIL_MAX_AGENTS; 0: the tail kernel does not apply.
+long tailLimit(const okenv *h, const bool q_launch)
+{
+    if (h->grid_mode != kGridLds || !h->coop || h->tail_max_agents == 0)
+        return 0;
+    const unsigned lanes = static_cast<unsigned>(((h->R * kTailSplit + 63) / 64) * 64);
+    const size_t   lds   = h->image_bytes + 16U + sizeof(float) * kTailLdsFloats + (q_launch ? qLdsBytes(h) : 0U);
+    if (lanes > 512U || lds > kLdsBudget)
+        return 0;
+    const long fit = static_cast<long>(kLdsBudget / lds) * 256L;
+    return h->tail_max_agents > 0 ? std::min<long>(h->tail_max_agents, fit) : fit;
 }
 
 // The step counter also lives on the device (it is the epoch of the auto-reset draws and must advance when a captured
@@ -1885,6 +1897,16 @@ extern "C"
             *alive_out = counts[0];
         if (listed_out)
             *listed_out = counts[1];
+        return OKENV_OK;
+    }
+
+    int okenv_episode_tail_limit(okenv_t h, int32_t *out)
+    {
+        OK_QUIESCE(h);
+        if (!h || !out)
+            return fail(h, OKENV_ERR_INVALID, "okenv_episode_tail_limit: NULL argument");
+        const bool q = h->ep_kind == kPolicyQ || (h->ep_kind == 0 && h->d_q_table != nullptr && h->d_mlp_w == nullptr);
+        *out         = static_cast<int32_t>(tailLimit(h, q));
         return OKENV_OK;
     }
 

@@ -304,6 +304,13 @@ class BatchedEnvironment:
         capi.check(self._L.okenv_episode_compact(self._h, C.byref(alive), C.byref(listed)), self._h)
         return alive.value, listed.value
 
+    def episode_tail_limit(self):
+        """Longest list that is stepped one agent per workgroup (okenv_episode_tail_limit): from there on one rollout call may ask
+        for all remaining steps."""
+        n = C.c_int32()
+        capi.check(self._L.okenv_episode_tail_limit(self._h, C.byref(n)), self._h)
+        return n.value
+
     def episode_end(self):
         """(steps of the reference's loop, live agent-steps); leaves the state as that loop leaves it."""
         steps, live = C.c_int32(), C.c_uint64()

@@ -38,13 +38,16 @@ class EvolutionaryRacer:
         e.reset_all(*self.start)
         e.step(1)  # initial observation (genetic_learner_sim.cpp:75)
         e.episode_begin()
-        steps = 0
+        tail = e.episode_tail_limit()
+        steps, listed = 0, e.N
         budget = self.max_steps - 1
         while steps < budget:
-            n = min(self.spl, budget - steps)
+            # once the list is short enough for one agent per workgroup, a workgroup leaves when its agent is done: ask for all the
+            # steps that are left -- the launch ends with the last crash, no more launch boundaries
+            n = budget - steps if listed <= tail else min(self.spl, budget - steps)
             e.rollout_policy(n)
             steps += n
-            alive, _ = e.episode_compact()
+            alive, listed = e.episode_compact()
             if alive == 0:
                 break
         loop_steps, self.live_agent_steps = e.episode_end()

@@ -26,12 +26,14 @@ class QLearningRacers:
         t0 = time.perf_counter()
         e.q_begin_episode(self.reset_idx)
         e.episode_begin()  # launches step the agents that can still change; crashed agents' -200 updates are settled at the end
-        steps = 0
+        tail = e.episode_tail_limit()
+        steps, listed = 0, e.N
         while steps < self.max_steps:
-            n = min(self.spl, self.max_steps - steps)
+            # (a short list is stepped one agent per workgroup, each leaving with its agent: one launch for all that is left)
+            n = self.max_steps - steps if listed <= tail else min(self.spl, self.max_steps - steps)
             e.rollout_q(n, float(self.epsilon), self.seed, self.agent_base, self.steps_total + steps)
             steps += n
-            alive, _ = e.episode_compact()
+            alive, listed = e.episode_compact()
             if alive == 0:
                 break
         steps, live = e.episode_end()  # the loop's own length: it ends with the step in which the last agent crashes

@@ -96,6 +96,34 @@ def test_ga_episode_lists_on_the_cooperative_kernel(gpu, oracle, monkeypatch, ta
     dev.close()
 
 
+def test_one_launch_for_the_whole_tail(gpu, oracle):
+    """what the drivers do: once the list is short enough for one agent per workgroup, ask for all the steps that are left in one
+    call (okenv_episode_tail_limit) -- the launch ends with the last crash; same step count, same state"""
+    t, dev, orc, ga = make_ga(gpu, oracle, "Spa", 200, 32)
+    start = (float(t.x[3]), float(t.y[3]), float(t.heading[0]))
+    dev.reset_all(*start)
+    ga.reset_all(*start)
+    dev.step(1)
+    orc.step(1)
+    want = oracle_ga_loop(orc, ga, 2500)
+    dev.episode_begin()
+    tail = dev.episode_tail_limit()
+    assert tail >= 256   # (Spa's image leaves room for one workgroup per CU)
+    taken, listed, calls = 0, dev.N, 0
+    while taken < 2500:
+        n = 2500 - taken if listed <= tail else min(40, 2500 - taken)
+        dev.rollout_policy(n)
+        taken += n
+        calls += 1
+        alive, listed = dev.episode_compact()
+        if alive == 0:
+            break
+    steps, live = dev.episode_end()
+    assert (steps, live) == want and calls == 1
+    assert_same_state(dev.snapshot(), orc.snapshot(), "one launch for the tail")
+    dev.close()
+
+
 def test_ga_episode_with_step_cap_and_agents_crashed_before_it_begins(gpu, oracle):
     """the caller's own cap ends the loop with agents alive: every step taken counts and nothing is put back; agents that are
     crashed when the episode begins are asked for an action once, like everybody else in the reference's loop"""

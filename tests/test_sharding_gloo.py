@@ -120,6 +120,7 @@ GA_WORKER = textwrap.dedent('''
         def alive_count(self): return self.ga.alive_count()
         # episodes (include/okenv.h): the reference's loop, which leaves with the step in which the last agent crashes
         def episode_begin(self): self._taken, self._T, self._live = 0, 0, 0
+        def episode_tail_limit(self): return 8   # (short lists: all remaining steps in one call)
         def rollout_policy(self, n):
             for _ in range(n):
                 alive = self.ga.alive_count()
