@@ -486,6 +486,14 @@ OKRC_HD uint32_t okShiftInSign(const uint32_t acc, const float d)
 //               decision of a pair is the sign of tol - |med3(side, side', 0)|, shifted into a bit accumulator
 //               (v_med3, v_sub, v_alignbit: no compare-to-mask round trip)
 //   exact loop  pairs whose accumulator bit AND break bit are clear, ok_first_hit_update
+//
+// skip_unowned_start: for walks that CONTINUE a ray somebody else has covered up to t_a (the intervals of a ray cut across
+// lanes; phase 2 after phase 1).  A walk over [t_x, t_a] ends with the cell in which it reaches t_a, so every cell the ray
+// ENTERED before t_a has been processed by the time this walk's turn comes -- and the cell that contains t_a is, as a rule, one
+// of them.  With the flag set the start cell is stepped over without being looked at when the ray entered it clearly before t_a
+// (by more than kOwnEps, far above the rounding of the crossing parameters, far below a cell): each cell of a ray is then
+// processed by the one walk in whose interval the ray enters it, instead of by two.  (A 25 px interval of a ray touches two or
+// three 24 px cells; the first of them is the neighbour's last.)  Must be false for the walk that starts a ray.
 template <bool kCount>
 OKRC_HD OkIntervalResult ok_cast_poly_interval(const OkPolyView &v,
                                                const float       ox,
@@ -497,7 +505,8 @@ OKRC_HD OkIntervalResult ok_cast_poly_interval(const OkPolyView &v,
                                                uint32_t         *tests,
                                                uint32_t         *cells,
                                                uint32_t         *points,
-                                               unsigned long long *prof = nullptr)
+                                               unsigned long long *prof = nullptr,
+                                               const bool        skip_unowned_start = false)
 {
     const OkGridGeom &g = v.g;
     OKRC_PROF_BEGIN();
@@ -571,6 +580,27 @@ OKRC_HD OkIntervalResult ok_cast_poly_interval(const OkPolyView &v,
         leave  = (t_out <= t_exit) ? 1 : leave;                                                                        \
     } while (0)
 
+    {
+        // parameter at which the ray entered the start cell: the later of the two crossings before the upcoming ones (an axis
+        // the ray does not move along has none)
+        constexpr float kOwnEps = 1.0e-2F;
+        const float tprev_x = par_x ? -OKRC_INF : tmax_x - tdel_x;
+        const float tprev_y = par_y ? -OKRC_INF : tmax_y - tdel_y;
+        if (skip_unowned_start && __builtin_fmaxf(tprev_x, tprev_y) < t_a - kOwnEps)
+        { // the previous walk's: one step of the DDA, nothing read
+            const bool  go_x = tmax_x < tmax_y;
+            const float te   = __builtin_fminf(tmax_x, tmax_y);
+            left_x -= go_x ? 1 : 0;
+            left_y -= go_x ? 0 : 1;
+            if (t_out <= te || (left_x | left_y) < 0) // the range, the grid box or the grid ends inside that cell
+                return {OK_SENSOR_RANGE, OK_SENSOR_RANGE, true};
+            if (te >= t_b) // (an interval shorter than its start cell: every cell it touches is the previous walk's)
+                return {OK_SENSOR_RANGE, te, false};
+            cell += go_x ? lin_x : lin_y;
+            tmax_x = go_x ? tmax_x + tdel_x : tmax_x;
+            tmax_y = go_x ? tmax_y : tmax_y + tdel_y;
+        }
+    }
     OkCellHdr hc = v.hdr[cell];
     OKRC_ENTER_CELL();
     if (kCount)

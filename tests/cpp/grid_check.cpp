@@ -62,19 +62,32 @@ extern "C"
                 out_t[i] = ok_cast_ray_poly<true>(pv, ox[i], oy[i], c, s, &tests, &cells, &points);
             }
             else if (form >= 2)
-            { // the kernel's two-phase decomposition: [0, T1], then m equal sub-intervals of what is left
-                const float T1 = 48.0F;
-                const int   m  = form; // 2..8 sub-intervals
-                OkIntervalResult r1 = ok_cast_poly_interval<true>(pv, ox[i], oy[i], c, s, 0.0F, T1, &tests, &cells, &points);
-                float best = r1.min_t;
-                if (!r1.conclusive)
+            { // the kernels' decompositions of a ray:
+              //   form 2..8    the cooperative kernel: [0, T1], then m = form equal sub-intervals of what is left, every one of them
+              //                stepping over its start cell unless the ray enters it inside the interval (skip_unowned_start)
+              //   form 12..18  direct dealing / tail kernel: m = form - 10 equal intervals from the origin, all but the first stepping
+              //                over an unowned start cell
+              //   form 20 + m  m equal intervals from the origin, every one processing every cell it touches (the plain contract)
+                const bool plain = form >= 20, from_origin = form >= 10;
+                const int  m     = plain ? form - 20 : (from_origin ? form - 10 : form);
+                float      best = OK_SENSOR_RANGE, t0 = 0.0F;
+                bool       open = true;
+                if (!from_origin)
                 {
-                    const float dt = (OK_SENSOR_RANGE - r1.t_reached) / (float)m;
+                    OkIntervalResult r1 = ok_cast_poly_interval<true>(pv, ox[i], oy[i], c, s, 0.0F, 48.0F, &tests, &cells, &points);
+                    best = r1.min_t;
+                    open = !r1.conclusive;
+                    t0   = r1.t_reached;
+                }
+                if (open)
+                {
+                    const float dt = (OK_SENSOR_RANGE - t0) / (float)m;
                     for (int j = 0; j < m; ++j)
                     {
-                        const float ta = r1.t_reached + (float)j * dt;
-                        const float tb = (j == m - 1) ? OKRC_INF : ta + dt;
-                        OkIntervalResult r2 = ok_cast_poly_interval<true>(pv, ox[i], oy[i], c, s, ta, tb, &tests, &cells, &points);
+                        const float ta   = t0 + (float)j * dt;
+                        const float tb   = (j == m - 1) ? OKRC_INF : t0 + (float)(j + 1) * dt;
+                        const bool  skip = !plain && (j > 0 || t0 > 0.0F);
+                        OkIntervalResult r2 = ok_cast_poly_interval<true>(pv, ox[i], oy[i], c, s, ta, tb, &tests, &cells, &points, nullptr, skip);
                         best = r2.min_t < best ? r2.min_t : best;
                     }
                 }

@@ -49,7 +49,9 @@ def make_rays(t, n, seed):
     return ox, oy, ang
 
 
-@pytest.mark.parametrize("form", [0, 1, 2, 4, 7])
+# forms (tests/cpp/grid_check.cpp): 0 wide grid, 1 one walk per ray, 2..8 phase 1 + that many intervals with the start-cell ownership
+# rule (the cooperative kernel), 12..18 form - 10 intervals from the origin with it (direct dealing, tail kernel), 20 + m: m plain intervals
+@pytest.mark.parametrize("form", [0, 1, 2, 4, 7, 8, 12, 13, 18, 23, 27])
 @pytest.mark.parametrize("name,cell", [("Silverstone", 16.0), ("Silverstone", 7.0), ("Spa", 16.0), ("Austin", 33.0), ("Monza", 300.0)])
 def test_grid_walk_equals_brute_force(oracle, gridcheck, name, cell, form):
     t = O.Track(name)
@@ -88,7 +90,7 @@ def test_degenerate_segment_sets(oracle, gridcheck):
         tests, cells, points = (np.zeros(n, dtype=np.uint32) for _ in range(3))
         want = np.array([O.lib().oracle_cast_ray(float(ox[i]), float(oy[i]), float(ang[i]), flat, segs.shape[0]) for i in range(n)],
                         dtype=np.float32)
-        for form in (0, 1, 3):
+        for form in (0, 1, 3, 8, 12, 18, 25):
             assert gridcheck.gridcheck_cast(flat, segs.shape[0], 16.0, ox, oy, ang, n, got, tests, cells, info, form, points) == 0
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), form
 

@@ -35,13 +35,25 @@ struct LaneTrace
 };
 
 // ok_cast_poly_interval with recording (same control flow)
-LaneTrace traceInterval(const OkPolyView &v, float ox, float oy, float rdx, float rdy, float t_a, float t_b, int pair_batch)
+// skip_cells / max_cells: the cell-task form of phase 2 -- start the walk at t_a, step over `skip_cells` cells without looking
+// at them, process at most `max_cells` cells (t_reached = the last one's exit; conclusive as usual or when the walk ended)
+LaneTrace traceInterval(const OkPolyView &v, float ox, float oy, float rdx, float rdy, float t_a, float t_b, int pair_batch,
+                        int skip_cells = 0, int max_cells = 1 << 30)
 {
     LaneTrace         tr;
     const OkGridGeom &g = v.g;
     OkWalk            w;
     if (!w.init(g, ox, oy, rdx, rdy, t_a))
         return tr;
+    for (int k = 0; k < skip_cells; ++k)
+    {
+        if (w.t_out <= w.exitT() || !w.advance(g))
+        { // the range or the grid ends before this lane's cell: nothing to do, the ray is covered to the end
+            tr.t_reached  = OK_SENSOR_RANGE;
+            tr.conclusive = true;
+            return tr;
+        }
+    }
     const float tol   = v.side_tol;
     float       min_t = OK_SENSOR_RANGE;
     OkCellHdr   h     = v.hdr[w.iy * g.nx + w.ix];
@@ -100,7 +112,7 @@ LaneTrace traceInterval(const OkPolyView &v, float ox, float oy, float rdx, floa
             tr.conclusive = true;
             return tr;
         }
-        if (t_exit >= t_b)
+        if (t_exit >= t_b || --max_cells <= 0)
         {
             tr.t_reached  = t_exit;
             tr.conclusive = false;
@@ -117,6 +129,10 @@ LaneTrace traceInterval(const OkPolyView &v, float ox, float oy, float rdx, floa
     tr.conclusive = true;
     return tr;
 }
+
+int g_cells_goal = 0; // cell tasks: cells a round should cover per ray (0: one cell per lane)
+int g_p2_mode = 0; // 0: equal parameter intervals (shipped), 1: cell tasks (lane j of a ray takes the j-th cell after t_reached), rounds until done
+double g_p2_rounds = 0;
 
 struct WaveCount
 {
@@ -157,6 +173,12 @@ struct WaveCount
     }
 };
 } // namespace
+
+extern "C" __attribute__((visibility("default"))) void wavemodel_set_p2_mode(int mode, int cells_goal)
+{
+    g_p2_mode    = mode;
+    g_cells_goal = cells_goal;
+}
 
 extern "C" __attribute__((visibility("default"))) int wavemodel_run(const float *segs_xyxy,
                                                                      int          S,
@@ -201,7 +223,50 @@ extern "C" __attribute__((visibility("default"))) int wavemodel_run(const float 
                 pend.push_back(r);
         }
         p1.add(l1);
-        if (!pend.empty())
+        if (!pend.empty() && g_p2_mode == 1)
+        {
+            waves_with_p2 += 1;
+            n_pending += pend.size();
+            std::vector<float> t0(64), mt(64);
+            std::vector<int>   done(64, 0);
+            for (int r : pend)
+            {
+                t0[r] = l1[r].t_reached;
+                mt[r] = l1[r].min_t;
+            }
+            while (!pend.empty())
+            {
+                g_p2_rounds += 1;
+                const int n = static_cast<int>(pend.size());
+                int       m = 64 / n;
+                m           = m > max_split ? max_split : m;
+                const int c = g_cells_goal > 0 ? (g_cells_goal + m - 1) / m : 1; // consecutive cells per lane
+                std::vector<LaneTrace> l2;
+                std::vector<int>       next;
+                for (int q = 0; q < n; ++q)
+                {
+                    const int r       = pend[q];
+                    float     reached = t0[r];
+                    bool      ended   = false;
+                    for (int j = 0; j < m; ++j)
+                    {
+                        LaneTrace t = traceInterval(pv, ox, oy, dx[r], dy[r], t0[r], OKRC_INF, pair_batch, done[r] + j * c, c);
+                        mt[r]       = std::min(mt[r], t.min_t);
+                        if (t.conclusive && t.t_reached >= OK_SENSOR_RANGE)
+                            ended = true;
+                        reached = std::max(reached, t.t_reached);
+                        l2.push_back(std::move(t));
+                    }
+                    // (a walk restarted at a cell's exit parameter may land in the cell just left: one cell of overlap per round)
+                    done[r] += m * c;
+                    if (!(ended || mt[r] <= reached))
+                        next.push_back(r);
+                }
+                p2.add(l2);
+                pend.swap(next);
+            }
+        }
+        else if (!pend.empty())
         {
             waves_with_p2 += 1;
             n_pending += pend.size();
@@ -231,6 +296,9 @@ extern "C" __attribute__((visibility("default"))) int wavemodel_run(const float 
     *o++ = p2.cell_it / W;  *o++ = p2.chunk_it / W;  *o++ = p2.pair_it / W;  *o++ = p2.exact_it / W;
     *o++ = p2.cell_lanes / W;  *o++ = p2.chunk_lanes / W;  *o++ = p2.pair_lanes / W;  *o++ = p2.exact_lanes / W;
     *o++ = n_pending / W;  *o++ = waves_with_p2 / W;  *o++ = static_cast<double>(img.bytes.size());  *o++ = img.max_slots_per_cell;
+    if (g_p2_mode == 1)
+        std::printf("    phase-2 rounds per wave-step: %.2f\n", g_p2_rounds / W);
+    g_p2_rounds = 0;
     std::printf("    exact tests per wave-step by outcome: accepted %.1f behind %.1f beyond-hit %.1f s-outside %.1f parallel %.1f\n", g_cls[0] / W, g_cls[1] / W, g_cls[2] / W, g_cls[3] / W, g_cls[4] / W);
     return 0;
 }

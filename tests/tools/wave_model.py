@@ -49,7 +49,12 @@ def main():
     print("%s: %d live poses, %d rays" % (tname, px.size, R))
     hdr = ("(pairs column = 8-slot rounds)\ncell  T1 split pb |  p1: cells chunks pairs exact (util: cell pair exact) |  p2: cells chunks pairs exact (util) | pend  p2frac | image")
     print(hdr)
-    for cell, t1, split, pb in [(20, 48, 8, 1), (24, 48, 8, 1), (24, 40, 8, 1), (24, 56, 8, 1), (28, 48, 8, 1), (20, 48, 16, 1)]:
+    mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    goal = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    L.wavemodel_set_p2_mode(mode, goal)
+    print("cells per round and ray (goal): %d" % goal)
+    print("phase 2: %s" % ("cell tasks (lane j of a ray takes its j-th cell after phase 1; rounds until done)" if mode else "equal parameter intervals (shipped)"))
+    for cell, t1, split, pb in [(20, 48, 8, 1), (24, 48, 8, 1), (24, 40, 8, 1), (24, 32, 8, 1), (24, 24, 8, 1), (24, 56, 8, 1), (28, 48, 8, 1)]:
         out = np.zeros(20)
         rc = L.wavemodel_run(track.segments, track.S, float(cell), px, py, rot, px.size, fan, R, float(t1), split, pb, out)
         if rc != 0:
