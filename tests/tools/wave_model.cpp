@@ -21,6 +21,7 @@ struct ChunkRec
 {
     uint16_t pairs;  // point-pair iterations of the chunk
     uint16_t exact;  // exact tests run after it
+    uint16_t slots;  // slots of the chunk
 };
 struct CellRec
 {
@@ -38,13 +39,33 @@ struct LaneTrace
 // skip_cells / max_cells: the cell-task form of phase 2 -- start the walk at t_a, step over `skip_cells` cells without looking
 // at them, process at most `max_cells` cells (t_reached = the last one's exit; conclusive as usual or when the walk ended)
 LaneTrace traceInterval(const OkPolyView &v, float ox, float oy, float rdx, float rdy, float t_a, float t_b, int pair_batch,
-                        int skip_cells = 0, int max_cells = 1 << 30)
+                        int skip_cells = 0, int max_cells = 1 << 30, bool skip_unowned_start = false)
 {
     LaneTrace         tr;
     const OkGridGeom &g = v.g;
     OkWalk            w;
     if (!w.init(g, ox, oy, rdx, rdy, t_a))
         return tr;
+    if (skip_unowned_start)
+    { // the shipped rule (ok_cast_poly_interval): the start cell is the previous walk's when the ray entered it before t_a
+        const float px = (w.tdel_x < OKRC_INF) ? w.tmax_x - w.tdel_x : -OKRC_INF, py = (w.tdel_y < OKRC_INF) ? w.tmax_y - w.tdel_y : -OKRC_INF;
+        if (std::max(px, py) < t_a - 1.0e-2F)
+        {
+            const float te = w.exitT();
+            if (w.t_out <= te || !w.advance(g))
+            {
+                tr.t_reached  = OK_SENSOR_RANGE;
+                tr.conclusive = true;
+                return tr;
+            }
+            if (te >= t_b)
+            {
+                tr.t_reached  = te;
+                tr.conclusive = false;
+                return tr;
+            }
+        }
+    }
     for (int k = 0; k < skip_cells; ++k)
     {
         if (w.t_out <= w.exitT() || !w.advance(g))
@@ -78,7 +99,8 @@ LaneTrace traceInterval(const OkPolyView &v, float ox, float oy, float rdx, floa
                 }
             uint32_t       cand = ~(skip | hc.brk);
             const uint32_t top  = k0 + ((n + 7U) & ~7U) - 2U;
-            ChunkRec c{static_cast<uint16_t>((n + 8 * pair_batch - 1) / (8 * pair_batch)), static_cast<uint16_t>(__builtin_popcount(cand))};
+            ChunkRec c{static_cast<uint16_t>((n + 8 * pair_batch - 1) / (8 * pair_batch)), static_cast<uint16_t>(__builtin_popcount(cand)),
+                       static_cast<uint16_t>(n)};
             while (cand != 0U)
             {
                 const uint32_t z = static_cast<uint32_t>(__builtin_clz(cand));
@@ -131,12 +153,13 @@ LaneTrace traceInterval(const OkPolyView &v, float ox, float oy, float rdx, floa
 }
 
 int g_cells_goal = 0; // cell tasks: cells a round should cover per ray (0: one cell per lane)
-int g_p2_mode = 0; // 0: equal parameter intervals (shipped), 1: cell tasks (lane j of a ray takes the j-th cell after t_reached), rounds until done
+int g_p2_mode = 0; // 0: equal parameter intervals with the start-cell ownership rule (shipped), 2: without it (round 2), 1: cell tasks (lane j of a ray takes the j-th cell after t_reached), rounds until done
 double g_p2_rounds = 0;
 
 struct WaveCount
 {
     double cell_it = 0, chunk_it = 0, pair_it = 0, exact_it = 0;             // lock-step iterations
+    double half_it = 0;                                                      // point loop in rounds of FOUR slots
     double cell_lanes = 0, chunk_lanes = 0, pair_lanes = 0, exact_lanes = 0; // active lane-iterations
     void   add(const std::vector<LaneTrace> &lanes)
     {
@@ -156,17 +179,19 @@ struct WaveCount
             for (size_t k = 0; k < max_chunks; ++k)
             {
                 chunk_it += 1;
-                int mp = 0, me = 0;
+                int mp = 0, me = 0, mh = 0;
                 for (auto &l : lanes)
                     if (c < l.cells.size() && k < l.cells[c].chunks.size())
                     {
                         chunk_lanes += 1;
                         mp = std::max<int>(mp, l.cells[c].chunks[k].pairs);
+                        mh = std::max<int>(mh, (l.cells[c].chunks[k].slots + 3) / 4);
                         me = std::max<int>(me, l.cells[c].chunks[k].exact);
                         pair_lanes += l.cells[c].chunks[k].pairs;
                         exact_lanes += l.cells[c].chunks[k].exact;
                     }
                 pair_it += mp;
+                half_it += mh;
                 exact_it += me;
             }
         }
@@ -284,7 +309,7 @@ extern "C" __attribute__((visibility("default"))) int wavemodel_run(const float 
                 const float dt = (OK_SENSOR_RANGE - t0) / static_cast<float>(m);
                 const float ta = t0 + static_cast<float>(j) * dt;
                 const float tb = (j + 1 == m) ? OKRC_INF : t0 + static_cast<float>(j + 1) * dt;
-                l2.push_back(traceInterval(pv, ox, oy, dx[r], dy[r], ta, tb, pair_batch));
+                l2.push_back(traceInterval(pv, ox, oy, dx[r], dy[r], ta, tb, pair_batch, 0, 1 << 30, g_p2_mode == 0));
             }
             p2.add(l2);
         }
@@ -296,6 +321,8 @@ extern "C" __attribute__((visibility("default"))) int wavemodel_run(const float 
     *o++ = p2.cell_it / W;  *o++ = p2.chunk_it / W;  *o++ = p2.pair_it / W;  *o++ = p2.exact_it / W;
     *o++ = p2.cell_lanes / W;  *o++ = p2.chunk_lanes / W;  *o++ = p2.pair_lanes / W;  *o++ = p2.exact_lanes / W;
     *o++ = n_pending / W;  *o++ = waves_with_p2 / W;  *o++ = static_cast<double>(img.bytes.size());  *o++ = img.max_slots_per_cell;
+    std::printf("    point loop: %.2f + %.2f rounds of 8 slots per wave-step; in rounds of 4 slots: %.2f + %.2f (= %.2f + %.2f of 8)\n", p1.pair_it / W, p2.pair_it / W,
+                p1.half_it / W, p2.half_it / W, p1.half_it / W / 2, p2.half_it / W / 2);
     if (g_p2_mode == 1)
         std::printf("    phase-2 rounds per wave-step: %.2f\n", g_p2_rounds / W);
     g_p2_rounds = 0;

@@ -53,7 +53,8 @@ def main():
     goal = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     L.wavemodel_set_p2_mode(mode, goal)
     print("cells per round and ray (goal): %d" % goal)
-    print("phase 2: %s" % ("cell tasks (lane j of a ray takes its j-th cell after phase 1; rounds until done)" if mode else "equal parameter intervals (shipped)"))
+    print("phase 2: %s" % {0: "equal parameter intervals, start cells owned by one walk (shipped)", 1: "cell tasks (lane j of a ray takes cells after phase 1; rounds until done)",
+                           2: "equal parameter intervals, every walk processes every cell it touches (round 2)"}[mode])
     for cell, t1, split, pb in [(20, 48, 8, 1), (24, 48, 8, 1), (24, 40, 8, 1), (24, 32, 8, 1), (24, 24, 8, 1), (24, 56, 8, 1), (28, 48, 8, 1)]:
         out = np.zeros(20)
         rc = L.wavemodel_run(track.segments, track.S, float(cell), px, py, rot, px.size, fan, R, float(t1), split, pb, out)
