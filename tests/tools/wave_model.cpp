@@ -152,6 +152,7 @@ LaneTrace traceInterval(const OkPolyView &v, float ox, float oy, float rdx, floa
     return tr;
 }
 
+int g_p1_max_cells = 0; // phase 1 ends after this many cells at the latest (0: at its range only)
 int g_cells_goal = 0; // cell tasks: cells a round should cover per ray (0: one cell per lane)
 int g_p2_mode = 0; // 0: equal parameter intervals with the start-cell ownership rule (shipped), 2: without it (round 2), 1: cell tasks (lane j of a ray takes the j-th cell after t_reached), rounds until done
 double g_p2_rounds = 0;
@@ -199,10 +200,11 @@ struct WaveCount
 };
 } // namespace
 
-extern "C" __attribute__((visibility("default"))) void wavemodel_set_p2_mode(int mode, int cells_goal)
+extern "C" __attribute__((visibility("default"))) void wavemodel_set_p2_mode(int mode, int cells_goal, int p1_max_cells)
 {
-    g_p2_mode    = mode;
-    g_cells_goal = cells_goal;
+    g_p2_mode      = mode;
+    g_cells_goal   = cells_goal;
+    g_p1_max_cells = p1_max_cells;
 }
 
 extern "C" __attribute__((visibility("default"))) int wavemodel_run(const float *segs_xyxy,
@@ -243,7 +245,7 @@ extern "C" __attribute__((visibility("default"))) int wavemodel_run(const float 
         for (int r = 0; r < R; ++r)
         {
             ok_sincosf(OK_DEG2RAD * (rot_deg[a] + ray_deg[r]), &dy[r], &dx[r]);
-            l1[r] = traceInterval(pv, ox, oy, dx[r], dy[r], 0.F, phase1_range, pair_batch);
+            l1[r] = traceInterval(pv, ox, oy, dx[r], dy[r], 0.F, phase1_range, pair_batch, 0, g_p1_max_cells > 0 ? g_p1_max_cells : (1 << 30));
             if (!l1[r].conclusive)
                 pend.push_back(r);
         }
