@@ -401,7 +401,8 @@ __device__ __forceinline__ void okAgentPreStep(const OkStepParams &p,
                                                float              *ray_sn  = nullptr,
                                                float              *ray_cs  = nullptr,
                                                const bool          have_drawn = false,
-                                               const ok_random_action drawn = ok_random_action{}) // by value: a pointer here put it on the stack
+                                               const ok_random_action drawn = ok_random_action{}, // by value: a pointer here put it on the stack
+                                               const bool          pair_split = false)
 {
     if ((p.reset_flags & kAutoResetOn) != 0U && r.crashed)
     {
@@ -459,9 +460,25 @@ __device__ __forceinline__ void okAgentPreStep(const OkStepParams &p,
     // The lane's ray direction (CollisionChecker.cu:125, angle = kDeg2Rad * (rot_ + ray angle)) depends on nothing but
     // the heading just updated: evaluated here, next to the agent's own sine/cosine, the two independent fp64 chains
     // interleave instead of running back to back.
-    if (ray_sn != nullptr)
-        ok_sincosf(OK_DEG2RAD * (r.rot + ray_deg), ray_sn, ray_cs);
-    ok_sincosf(OK_DEG2RAD * r.rot, &sn, &cs);
+    // pair_split (the tail kernel, where lanes 2i and 2i + 1 hold the same agent AND the same ray): the even lane takes the
+    // ray's angle, the odd lane the agent's, and they swap results -- one fp64 chain per lane instead of two.
+    if (pair_split)
+    {
+        const bool odd = (threadIdx.x & 1U) != 0U;
+        float      s1, c1;
+        ok_sincosf(odd ? OK_DEG2RAD * r.rot : OK_DEG2RAD * (r.rot + ray_deg), &s1, &c1);
+        const float s2 = okDppMove<kDppXor1>(s1), c2 = okDppMove<kDppXor1>(c1);
+        sn      = odd ? s1 : s2;
+        cs      = odd ? c1 : c2;
+        *ray_sn = odd ? s2 : s1;
+        *ray_cs = odd ? c2 : c1;
+    }
+    else
+    {
+        if (ray_sn != nullptr)
+            ok_sincosf(OK_DEG2RAD * (r.rot + ray_deg), ray_sn, ray_cs);
+        ok_sincosf(OK_DEG2RAD * r.rot, &sn, &cs);
+    }
     if (moves)
     {
         const float dx = cs * r.speed * OK_DT;
@@ -1597,7 +1614,9 @@ __global__ void __launch_bounds__(512) okStepTailKernel(const OkStepParams p, co
     uint32_t live_n  = 0U;
 #if defined(OKENV_STAMPS)
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long twalk[5] = {0, 0, 0, 0, 0}; // inside the walk: set-up, cell entry, point loop, exact loop, leaving the cell
     unsigned long long tlast   = __builtin_amdgcn_s_memtime();
+#define OK_TWALK twalk
     tacc[2]                    = __builtin_amdgcn_s_memrealtime();
 #define OK_TSTAMP(i)                                                                                                   \
     do                                                                                                                 \
@@ -1608,6 +1627,7 @@ __global__ void __launch_bounds__(512) okStepTailKernel(const OkStepParams p, co
     } while (0)
 #else
 #define OK_TSTAMP(i)
+#define OK_TWALK nullptr
 #endif
     for (int s = 0; s < p.n_steps; ++s)
     {
@@ -1658,7 +1678,8 @@ __global__ void __launch_bounds__(512) okStepTailKernel(const OkStepParams p, co
         }
         OK_TSTAMP(0);
         float sr, cr, rdx = 1.F, rdy = 0.F;
-        okAgentPreStep(p, ag, a, s, sr, cr, ray_deg, &rdy, &rdx);
+        static_assert(kTailSplit % 2 == 0, "lanes 2i and 2i + 1 share a ray");
+        okAgentPreStep(p, ag, a, s, sr, cr, ray_deg, &rdy, &rdx, false, ok_random_action{}, true);
         const float ox    = ag.pos_x + p.sensor_offset * cr;
         const float oy    = ag.pos_y + p.sensor_offset * sr;
         const bool  casts = ray_ok && !ag.crashed;
@@ -1670,7 +1691,7 @@ __global__ void __launch_bounds__(512) okStepTailKernel(const OkStepParams p, co
             const float dt = OK_SENSOR_RANGE * okRcpApprox(static_cast<float>(kTailSplit));
             const float ta = static_cast<float>(part) * dt;
             const float tb = (part + 1 == kTailSplit) ? OKRC_INF : static_cast<float>(part + 1) * dt;
-            found          = ok_cast_poly_interval<false>(view, ox, oy, rdx, rdy, ta, tb, nullptr, nullptr, nullptr, nullptr, part > 0).min_t;
+            found          = ok_cast_poly_interval<false>(view, ox, oy, rdx, rdy, ta, tb, nullptr, nullptr, nullptr, OK_TWALK, part > 0).min_t;
         }
         found = okGroupMin(found, kTailSplit);
         OK_TSTAMP(3);
@@ -1760,6 +1781,9 @@ __global__ void __launch_bounds__(512) okStepTailKernel(const OkStepParams p, co
     if (lane == 0 && p.stamps != nullptr)
         for (int i = 0; i < 8; ++i)
             p.stamps[(static_cast<long>(blockIdx.x) * n_waves + wave) * kStampWords + i] = tacc[i];
+    if (lane == 0 && p.stamps != nullptr)
+        for (int i = 0; i < 5; ++i)
+            p.stamps[(static_cast<long>(blockIdx.x) * n_waves + wave) * kStampWords + 8 + i] = twalk[i];
 #endif
     if (L == 0)
     {

@@ -4,9 +4,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
 import numpy as np
-if os.environ.get("OKENV_STAMPS_LIB"):
+if os.environ.get("OKENV_STAMPS_LIB") or os.environ.get("OKENV_LIB"):  # a variant from tools/build_variant.sh (the former: built with -DOKENV_STAMPS)
     import openkitchen_amd.buildlib as bl
-    bl.LIB_PATH = os.path.abspath(os.environ["OKENV_STAMPS_LIB"]); bl.needs_build = lambda: False
+    bl.LIB_PATH = os.path.abspath(os.environ.get("OKENV_STAMPS_LIB") or os.environ["OKENV_LIB"]); bl.needs_build = lambda: False
 import openkitchen_amd as ok
 
 def run(cfg, N, tail):
@@ -41,6 +41,7 @@ def run(cfg, N, tail):
         o = out[:n].astype(np.float64) / 40.0
         print("    stamps (cycles per wave-step, mean over %d waves): policy %.0f pre-step %.0f walk %.0f epilogue %.0f barrier %.0f crash+Q %.0f ; sum %.0f"
               % (n, o[:, 0].mean(), o[:, 1].mean(), o[:, 3].mean(), o[:, 5].mean(), o[:, 6].mean(), o[:, 7].mean(), o[:, [0, 1, 3, 5, 6, 7]].sum(axis=1).mean()))
+        print("    inside the walk: set-up %.0f cell entry %.0f point loop %.0f exact loop %.0f leaving %.0f" % tuple(o[:, 8 + i].mean() for i in range(5)))
     env.close()
 
 sizes = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [8, 64, 256, 512, 768, 1024]
