@@ -331,3 +331,76 @@ extern "C" __attribute__((visibility("default"))) int wavemodel_run(const float 
     std::printf("    exact tests per wave-step by outcome: accepted %.1f behind %.1f beyond-hit %.1f s-outside %.1f parallel %.1f\n", g_cls[0] / W, g_cls[1] / W, g_cls[2] / W, g_cls[3] / W, g_cls[4] / W);
     return 0;
 }
+
+// The tail kernel's arrangement (okStepTailKernel): one agent per workgroup, `split` equal pieces per ray with the ownership rule,
+// eight rays (consecutive, or strided over the waves) per wave.  Prints, per agent-step, the lock-step counts of the mean wave and
+// of the critical wave (the one with the largest modelled cost: the step waits for it at the barrier).
+extern "C" __attribute__((visibility("default"))) int wavemodel_tail(const float *segs_xyxy, int S, float cell, const float *pos_x, const float *pos_y,
+                                                                      const float *rot_deg, int n_agents, const float *ray_deg, int R, int split,
+                                                                      int strided, int slot_lanes)
+{
+    const OkSeg *segs = reinterpret_cast<const OkSeg *>(segs_xyxy);
+    OkGridHost   gh   = okBuildGrid(segs, static_cast<size_t>(S), cell);
+    OkPolyImage  img  = okBuildPolyImage(segs, static_cast<size_t>(S), gh);
+    if (!img.ok)
+        return -1;
+    OkPolyView pv{};
+    pv.g        = gh.g;
+    pv.slots    = reinterpret_cast<const OkPoint *>(img.bytes.data());
+    pv.hdr      = reinterpret_cast<const OkCellHdr *>(img.bytes.data() + img.off_hdr);
+    pv.side_tol = img.side_tol;
+    const int rays_per_wave = 64 / split, n_waves = (R + rays_per_wave - 1) / rays_per_wave;
+    auto cost = [&](const WaveCount &w) { return 150.0 * w.cell_it + 300.0 * (slot_lanes > 1 ? w.half_it * 4.0 / (8.0 * slot_lanes) * 2.0 : w.pair_it) + 450.0 * w.exact_it; };
+    WaveCount mean_w, crit_w;
+    double    mean_cost = 0, crit_cost = 0, first_cell_exact = 0, first_cell_pairs = 0;
+    for (double &x : g_cls) x = 0;
+    for (int a = 0; a < n_agents; ++a)
+    {
+        const float ox = pos_x[a], oy = pos_y[a];
+        WaveCount   worst;
+        double      worst_cost = -1;
+        for (int w = 0; w < n_waves; ++w)
+        {
+            std::vector<LaneTrace> lanes;
+            for (int i = 0; i < rays_per_wave; ++i)
+            {
+                const int r = strided ? w + i * n_waves : w * rays_per_wave + i;
+                if (r >= R)
+                    continue;
+                float dx, dy;
+                ok_sincosf(OK_DEG2RAD * (rot_deg[a] + ray_deg[r]), &dy, &dx);
+                const float dt = OK_SENSOR_RANGE / static_cast<float>(split);
+                for (int j = 0; j < split; ++j)
+                {
+                    const float ta = static_cast<float>(j) * dt, tb = (j + 1 == split) ? OKRC_INF : static_cast<float>(j + 1) * dt;
+                    lanes.push_back(traceInterval(pv, ox, oy, dx, dy, ta, tb, 1, 0, 1 << 30, j > 0));
+                    if (j == 0 && !lanes.back().cells.empty())
+                        for (auto &c : lanes.back().cells[0].chunks)
+                        {
+                            first_cell_exact += c.exact;
+                            first_cell_pairs += c.pairs;
+                        }
+                }
+            }
+            WaveCount wc;
+            wc.add(lanes);
+            mean_w.cell_it += wc.cell_it; mean_w.pair_it += wc.pair_it; mean_w.exact_it += wc.exact_it; mean_w.half_it += wc.half_it;
+            mean_cost += cost(wc);
+            if (cost(wc) > worst_cost)
+            {
+                worst_cost = cost(wc);
+                worst      = wc;
+            }
+        }
+        crit_w.cell_it += worst.cell_it; crit_w.pair_it += worst.pair_it; crit_w.exact_it += worst.exact_it; crit_w.half_it += worst.half_it;
+        crit_cost += worst_cost;
+    }
+    const double A = n_agents, W = A * n_waves;
+    std::printf("tail model cell %g split %d %s%s: mean wave: cells %.2f passes %.2f exact %.2f cost %.0f | critical wave: cells %.2f passes %.2f exact %.2f cost %.0f"
+                " | origin cell per ray: passes %.2f exact %.2f\n",
+                cell, split, strided ? "strided" : "consecutive", slot_lanes > 1 ? " slot-parallel" : "", mean_w.cell_it / W, mean_w.pair_it / W, mean_w.exact_it / W,
+                mean_cost / W, crit_w.cell_it / A, crit_w.pair_it / A, crit_w.exact_it / A, crit_cost / A, first_cell_pairs / (A * R), first_cell_exact / (A * R));
+    std::printf("    exact tests per agent-step by outcome: accepted %.1f behind %.1f beyond-hit %.1f s-outside %.1f parallel %.1f\n", g_cls[0] / A, g_cls[1] / A, g_cls[2] / A,
+                g_cls[3] / A, g_cls[4] / A);
+    return 0;
+}

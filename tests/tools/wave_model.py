@@ -47,6 +47,13 @@ def main():
     track = O.Track(tname)
     px, py, rot, fan = poses(track, N, R)
     print("%s: %d live poses, %d rays" % (tname, px.size, R))
+    if len(sys.argv) > 4 and sys.argv[4] == "tail":  # the tail kernel's arrangement: python wave_model.py Monza 256 32 tail
+        f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+        L.wavemodel_tail.argtypes = [f32p, C.c_int, C.c_float, f32p, f32p, f32p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int]
+        for cell in (20.0, 24.0, 16.0, 12.0):
+            for split, strided in ((8, 0), (8, 1), (16, 0), (4, 0)):
+                L.wavemodel_tail(track.segments, track.S, cell, px, py, rot, px.size, fan, R, split, strided, 1)
+        return
     hdr = ("(pairs column = 8-slot rounds)\ncell  T1 split pb |  p1: cells chunks pairs exact (util: cell pair exact) |  p2: cells chunks pairs exact (util) | pend  p2frac | image")
     print(hdr)
     mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
