@@ -172,10 +172,18 @@ int devAlloc(okenv *h, T **out, const size_t count)
 {
     void *p = nullptr;
     OK_HIP(h, hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    h->allocations.push_back(p); // (owned by the handle from here on, whatever happens next)
     OK_HIP(h, hipMemsetAsync(p, 0, std::max<size_t>(count, 1) * sizeof(T), h->stream));
-    h->allocations.push_back(p);
     *out = static_cast<T *>(p);
     return OKENV_OK;
+}
+
+// Buffers that are created on first use, in groups: each one is allocated if it is not there yet, so that a call which ran out of
+// memory half-way through its group can simply be repeated (the sizes depend on the handle's N and R only).
+template <class T>
+int devEnsure(okenv *h, T **out, const size_t count)
+{
+    return *out != nullptr ? OKENV_OK : devAlloc(h, out, count);
 }
 
 // Device staging space owned by the handle, grown on demand.  Each caller waits for the stream before it returns, so one
@@ -1781,13 +1789,11 @@ extern "C"
         OK_HIP(h, hipSetDevice(h->device));
         const size_t total = static_cast<size_t>(h->N) * OK_MLP_WEIGHTS(h->R);
         int          rc;
-        if (!h->d_mlp_w)
-        {
-            if ((rc = devAlloc(h, &h->d_mlp_w, total)) || (rc = devAlloc(h, &h->d_mlp_w_new, total)) ||
-                (rc = devAlloc(h, &h->d_score, static_cast<size_t>(h->N))) || (rc = devAlloc(h, &h->d_nearest, static_cast<size_t>(h->N))) ||
-                (rc = devAlloc(h, &h->d_parents, 16U)) || (rc = devAlloc(h, &h->d_parent_score, 16U)) || (rc = devAlloc(h, &h->d_alive, 4U)))
-                return rc;
-        }
+        // (d_mlp_w, which the other entry points take as "a policy exists", comes last)
+        if ((rc = devEnsure(h, &h->d_mlp_w_new, total)) || (rc = devEnsure(h, &h->d_score, static_cast<size_t>(h->N))) ||
+            (rc = devEnsure(h, &h->d_nearest, static_cast<size_t>(h->N))) || (rc = devEnsure(h, &h->d_parents, 16U)) ||
+            (rc = devEnsure(h, &h->d_parent_score, 16U)) || (rc = devEnsure(h, &h->d_alive, 4U)) || (rc = devEnsure(h, &h->d_mlp_w, total)))
+            return rc;
         h->mlp_hidden = hidden;
         hipLaunchKernelGGL(okGaInitWeightsKernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, h->stream, h->d_mlp_w, h->N,
                            h->R, hidden, seed, agent_base);
@@ -1864,13 +1870,10 @@ extern "C"
         OK_HIP(h, hipSetDevice(h->device));
         const size_t N = static_cast<size_t>(h->N);
         int          rc;
-        if (!h->d_settled)
-        {
-            if ((rc = devAlloc(h, &h->d_settled, N)) || (rc = devAlloc(h, &h->d_crash_step, N)) || (rc = devAlloc(h, &h->d_crash_thr, N)) ||
-                (rc = devAlloc(h, &h->d_crash_steer, N)) || (rc = devAlloc(h, &h->d_active, N)) || (rc = devAlloc(h, &h->d_ep_counts, 2U)) ||
-                (rc = devAlloc(h, &h->d_ep_out, 2U)) || (rc = devAlloc(h, &h->d_live, 1U)) || (rc = devAlloc(h, &h->d_q_next_state, N)))
-                return rc;
-        }
+        if ((rc = devEnsure(h, &h->d_settled, N)) || (rc = devEnsure(h, &h->d_crash_step, N)) || (rc = devEnsure(h, &h->d_crash_thr, N)) ||
+            (rc = devEnsure(h, &h->d_crash_steer, N)) || (rc = devEnsure(h, &h->d_active, N)) || (rc = devEnsure(h, &h->d_ep_counts, 2U)) ||
+            (rc = devEnsure(h, &h->d_ep_out, 2U)) || (rc = devEnsure(h, &h->d_live, 1U)) || (rc = devEnsure(h, &h->d_q_next_state, N)))
+            return rc;
         hipLaunchKernelGGL(okEpisodeBeginKernel, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->st.crashed, h->d_settled, h->d_crash_step,
                            h->d_live, h->N);
         OK_HIP(h, hipGetLastError());
@@ -2037,13 +2040,11 @@ extern "C"
         OK_HIP(h, hipSetDevice(h->device));
         const size_t n = static_cast<size_t>(h->N) * OK_Q_STATES * OK_Q_ACTIONS;
         int          rc;
-        if (!h->d_q_table)
-        {
-            if ((rc = devAlloc(h, &h->d_q_table, n)) || (rc = devAlloc(h, &h->d_q_state, static_cast<size_t>(h->N))) ||
-                (rc = devAlloc(h, &h->d_q_action, static_cast<size_t>(h->N))) || (rc = devAlloc(h, &h->d_q_prev, static_cast<size_t>(h->N))) ||
-                (rc = devAlloc(h, &h->d_q_reset_nearest, 4U)) || (rc = devAlloc(h, &h->d_q_reset_query, 4U)))
-                return rc;
-        }
+        // (d_q_table, which the other entry points take as "the tables exist", comes last)
+        if ((rc = devEnsure(h, &h->d_q_state, static_cast<size_t>(h->N))) || (rc = devEnsure(h, &h->d_q_action, static_cast<size_t>(h->N))) ||
+            (rc = devEnsure(h, &h->d_q_prev, static_cast<size_t>(h->N))) || (rc = devEnsure(h, &h->d_q_reset_nearest, 4U)) ||
+            (rc = devEnsure(h, &h->d_q_reset_query, 4U)) || (rc = devEnsure(h, &h->d_q_table, n)))
+            return rc;
         hipLaunchKernelGGL(okQInitTableKernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, h->stream, h->d_q_table,
                            static_cast<long>(n));
         OK_HIP(h, hipGetLastError());

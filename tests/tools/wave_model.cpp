@@ -161,6 +161,7 @@ struct WaveCount
 {
     double cell_it = 0, chunk_it = 0, pair_it = 0, exact_it = 0;             // lock-step iterations
     double half_it = 0;                                                      // point loop in rounds of FOUR slots
+    double pooled_it = 0;                                                    // exact loop if a chunk's candidates were pooled over the wave's lanes
     double cell_lanes = 0, chunk_lanes = 0, pair_lanes = 0, exact_lanes = 0; // active lane-iterations
     void   add(const std::vector<LaneTrace> &lanes)
     {
@@ -194,6 +195,13 @@ struct WaveCount
                 pair_it += mp;
                 half_it += mh;
                 exact_it += me;
+                {
+                    int tot = 0;
+                    for (auto &l : lanes)
+                        if (c < l.cells.size() && k < l.cells[c].chunks.size())
+                            tot += l.cells[c].chunks[k].exact;
+                    pooled_it += (tot + 63) / 64;
+                }
             }
         }
     }
@@ -325,6 +333,8 @@ extern "C" __attribute__((visibility("default"))) int wavemodel_run(const float 
     *o++ = n_pending / W;  *o++ = waves_with_p2 / W;  *o++ = static_cast<double>(img.bytes.size());  *o++ = img.max_slots_per_cell;
     std::printf("    point loop: %.2f + %.2f rounds of 8 slots per wave-step; in rounds of 4 slots: %.2f + %.2f (= %.2f + %.2f of 8)\n", p1.pair_it / W, p2.pair_it / W,
                 p1.half_it / W, p2.half_it / W, p1.half_it / W / 2, p2.half_it / W / 2);
+    std::printf("    exact loop if a chunk's candidates were pooled over the 64 lanes: %.2f + %.2f passes (now %.2f + %.2f)\n", p1.pooled_it / W, p2.pooled_it / W,
+                p1.exact_it / W, p2.exact_it / W);
     if (g_p2_mode == 1)
         std::printf("    phase-2 rounds per wave-step: %.2f\n", g_p2_rounds / W);
     g_p2_rounds = 0;
