@@ -233,8 +233,9 @@ def bench_callers(args, torch, local_rank, log):
     out["vector_env_torch_policy_graph"] = {"value": N * steps / dt, "unit": "agent-steps/s", "us_per_step": dt / steps * 1e6,
                                             "workload": "same iteration, captured into one HIP graph and replayed"}
     venv.close()
-    for key, fused in (("cmaes_generation", True), ("cmaes_generation_torch_controller", False)):
-        racers = CmaEsRacers(args.track, N, device=local_rank, seed=args.seed, max_steps=400, fused=fused)
+    for key, fused, rollout in (("cmaes_generation", True, True), ("cmaes_generation_three_calls_graph", True, False),
+                                ("cmaes_generation_torch_controller", False, False)):
+        racers = CmaEsRacers(args.track, N, device=local_rank, seed=args.seed, max_steps=400, fused=fused, rollout=rollout)
         racers.run_generation()  # warm-up (eigh, allocator, graph capture)
         gen_ms = []
         for _ in range(7):  # the GPU box stalls a process for ~75 ms about ten times a second (its monitor): median and min
@@ -244,23 +245,30 @@ def bench_callers(args, torch, local_rank, log):
             torch.cuda.synchronize()
             gen_ms.append((time.perf_counter() - t0) * 1e3)
         dt = float(np.median(gen_ms)) * 1e-3
-        # the loop alone: the iteration graph replayed on a freshly reset population, without sampling / eigh / tell (best of 4 x 100)
+        # the loop alone on a freshly reset population, without sampling / eigh / tell (best of 4 x 100 iterations): the iteration
+        # graph replayed, or -- the fused rollout -- one launch of 100 iterations
         racers.venv.reset(epoch=racers.generation)
         loop_us = []
         for _ in range(4):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(100):
-                racers._graph.replay()
+            if rollout:
+                racers.venv.env.rollout_controller(100, 100.0, 5.0)
+            else:
+                for _ in range(100):
+                    racers._graph.replay()
             torch.cuda.synchronize()
             loop_us.append((time.perf_counter() - t1) / 100 * 1e6)
         loop_dt = min(loop_us) * 1e-6 * gsteps
         out[key] = {
             "value": N * gsteps / dt, "unit": "agent-steps/s", "generation_ms": dt * 1e3, "generation_ms_min": min(gen_ms),
             "generations_timed": len(gen_ms), "steps": gsteps, "best_fitness": best, "loop_us_per_step": loop_dt / gsteps * 1e6,
-            "workload": "population %d (reference: 20), 250 parameters, controller 5-16-8-2 %s, iteration (controller, Environment::step, "
-                        "index-progress fitness) replayed as one HIP graph; generation_ms includes sampling and the host "
-                        "eigendecomposition of the 250 x 250 covariance" % (N, "as a libokenv kernel (okenv_controller_act)" if fused else "in PyTorch")}
+            "workload": "population %d (reference: 20), 250 parameters, controller 5-16-8-2 %s; generation_ms includes sampling and the host "
+                        "eigendecomposition of the 250 x 250 covariance"
+                        % (N, "fused with Environment::step and the index-progress fitness into the step kernel, the loop run as an episode "
+                              "(okenv_rollout_controller)" if rollout else
+                           ("as a libokenv kernel (okenv_controller_act), iteration (controller, Environment::step, index-progress fitness) "
+                            "replayed as one HIP graph" if fused else "in PyTorch, iteration replayed as one HIP graph"))}
         racers.venv.close()
     # the C++ drop-in classes (include/Environment/): microseconds per Environment::step() at the population sizes the
     # reference's applications use (Template 1, PPO / REINFORCE 15, EvolutionaryRacer 50 agents); five-ray fan

@@ -214,6 +214,14 @@ OKENV_API int okenv_controller_set_params(okenv_t h, const float *params);
  * step, throttle_delta = throttle, steering_delta = output[0] * steering_scale (100 and 5 in the reference).  One kernel on
  * the handle's stream, no synchronisation: it can be captured into a HIP graph next to okenv_step. */
 OKENV_API int okenv_controller_act(okenv_t h, float throttle, float steering_scale);
+/* The inner loop of the CMA-ES racers (main_eigen.cpp:135-160), n_steps iterations in ONE launch: for every agent
+ * { CmaEsAgent::updateAction (= okenv_controller_act); Environment::step; the fitness bookkeeping (= okenv_tracker_update) } with
+ * the controller, the step and the bookkeeping fused into the step kernel -- same results, bit for bit, as the three calls made
+ * n_steps times.  Needs okenv_controller_create, okenv_tracker_create (either reward kind) and the centre line.  Inside an
+ * episode (okenv_episode_begin / _compact / _end, below) later launches cover only the agents that can still change and
+ * okenv_episode_end returns the loop's own length, as for okenv_rollout_policy; episodes need OKENV_REWARD_PROGRESS (the +1
+ * reward keeps counting for crashed agents, which an episode no longer steps).  hidden <= 4 x the handle's lanes per agent. */
+OKENV_API int okenv_rollout_controller(okenv_t h, int32_t n_steps, float throttle, float steering_scale);
 
 /* ---- zero-copy access for device-side callers ------------------------ */
 

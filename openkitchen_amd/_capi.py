@@ -45,7 +45,7 @@ SYMBOLS = [
     "okenv_set_lane_bounds", "okenv_reset_random", "okenv_set_auto_reset", "okenv_get_step_count",
     "okenv_set_step_count", "okenv_field_device_ptr", "okenv_tracker_create", "okenv_tracker_begin",
     "okenv_tracker_update", "okenv_step_packed",
-    "okenv_controller_create", "okenv_controller_num_params", "okenv_controller_set_params", "okenv_controller_act",
+    "okenv_controller_create", "okenv_controller_num_params", "okenv_controller_set_params", "okenv_controller_act", "okenv_rollout_controller",
     "okenv_episode_begin", "okenv_episode_compact", "okenv_episode_end", "okenv_episode_tail_limit", "okenv_work_stats",
 ]
 
@@ -154,6 +154,7 @@ def load(build_if_missing=True):
     L.okenv_controller_num_params.argtypes = [vp, C.POINTER(C.c_int32)]
     L.okenv_controller_set_params.argtypes = [vp, vp]
     L.okenv_controller_act.argtypes = [vp, C.c_float, C.c_float]
+    L.okenv_rollout_controller.argtypes = [vp, C.c_int32, C.c_float, C.c_float]
     L.okenv_tracker_create.argtypes = [vp, i32]
     L.okenv_tracker_begin.argtypes = [vp]
     L.okenv_tracker_update.argtypes = [vp]

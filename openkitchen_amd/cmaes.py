@@ -5,9 +5,12 @@ Mirror of the reference's CovarianceMatrixAdaptationEvolution app for N candidat
   * `BatchedController`-- Controller.cpp:3-23, one parameter vector per candidate, evaluated for all candidates at once
   * `CmaEsRacers`      -- the generation loop of main_eigen.cpp:113-171: sample, resetAgent, one observation step, then
                           {updateAction; env.step(); fitness += |index progress|} until every candidate has crashed.
-The environment step, the candidates' controllers and the fitness bookkeeping are libokenv.so kernels (okenv_step,
-okenv_controller_act, okenv_tracker_update): three launches per iteration, replayed as one HIP graph.  `fused=False`
-evaluates the controllers in plain PyTorch instead (`BatchedController`, a dozen small kernels per iteration).  The reference seeds std::mt19937 from std::random_device
+The environment step, the candidates' controllers and the fitness bookkeeping run on the device.  By default the whole inner loop
+is ONE kernel per launch (okenv_rollout_controller: controller, Environment::step and bookkeeping fused into the step kernel, as an
+episode -- later launches cover the candidates that can still change, the loop's own length comes back); `rollout=False` makes the
+three calls per iteration (okenv_controller_act, okenv_step, okenv_tracker_update), replayed as one HIP graph; `fused=False`
+evaluates the controllers in plain PyTorch instead (`BatchedController`, a dozen small kernels per iteration).  All three give the
+same fitness bit for bit except the PyTorch controllers (their tanh and summation order are torch's).  The reference seeds std::mt19937 from std::random_device
 (CmaEsSolverEigen.h:49), so its sample streams are not reproducible; here a seeded numpy Generator draws z.
 """
 import contextlib
@@ -146,11 +149,14 @@ class CmaEsRacers:
     RAYS = (-70.0, -30.0, 0.0, 30.0, 70.0)  # CmaEsAgent's fan (main_eigen.cpp:26-31)
     HIDDEN, OUTPUTS = 16, 2                  # main_eigen.cpp:18-19
 
-    def __init__(self, track, population_size=20, device=0, seed=0, reset_randomly=False, max_steps=None, fused=True):
+    def __init__(self, track, population_size=20, device=0, seed=0, reset_randomly=False, max_steps=None, fused=True, rollout=True,
+                 steps_per_launch=100):
         self.venv = VectorEnvironment(track, population_size, ray_angles_deg=np.array(self.RAYS, dtype=np.float32),
                                       device=device, movement_mode=capi.MODE_VELOCITY, auto_reset=False,
                                       pick_random_point=reset_randomly, seed=seed, reward="progress")
         self.fused = bool(fused)
+        self.rollout = bool(rollout) and self.fused
+        self.steps_per_launch = int(steps_per_launch)
         self.controller = BatchedController(len(self.RAYS), self.HIDDEN, self.OUTPUTS, self.venv.device, population_size)
         if self.fused:
             assert self.venv.env.controller_create(self.HIDDEN) == self.controller.count_params()
@@ -180,6 +186,22 @@ class CmaEsRacers:
         self.update_action()
         self.venv.step()
 
+    def _rollout_episode(self):
+        """main_eigen.cpp:135-160 until every candidate has crashed (or max_steps): returns the loop's own length."""
+        env = self.venv.env
+        env.episode_begin()
+        budget = self.max_steps if self.max_steps is not None else 1 << 30
+        taken = 0
+        while taken < budget:
+            n = min(self.steps_per_launch, budget - taken)
+            env.rollout_controller(n, 100.0, 5.0)
+            taken += n
+            alive, _ = env.episode_compact()
+            if alive == 0:
+                break
+        steps, self.live_agent_steps = env.episode_end()
+        return steps
+
     def run_generation(self, check_every=16, use_graph=True):
         """One pass of the while(true) body, main_eigen.cpp:113-182; returns (best fitness, steps taken).  The loop
         iteration (controller forward, env.step(), fitness bookkeeping: a dozen small kernels) is captured once into a
@@ -187,6 +209,15 @@ class CmaEsRacers:
         venv = self.venv
         population = self.solver.sample()
         self.set_params(population)
+        if self.rollout:
+            # resetAgent for every candidate, the initial-observation step, prev_track_idx_ (main_eigen.cpp:120-133), then the
+            # while (!all_done) loop as an episode of fused launches
+            venv.reset(epoch=self.generation)
+            steps = self._rollout_episode()
+            fitness = venv.fitness.cpu().numpy().astype(np.float64)
+            self.solver.tell(population, fitness)
+            self.generation += 1
+            return float(fitness.max()), steps
         if use_graph and self._graph is None:
             self._graph = venv.capture(self._iteration, warmup=2)
         # resetAgent for every candidate, the initial-observation step, prev_track_idx_ (main_eigen.cpp:120-133)

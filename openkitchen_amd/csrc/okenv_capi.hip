@@ -295,6 +295,11 @@ OkStepParams baseParams(okenv *h)
     for (int i = 0; i < 5; ++i)
         p.q_ray[i] = h->q_ray[i];
     p.q_epsilon = h->q_epsilon;
+    p.ctrl_params     = h->d_ctrl_params;
+    p.ctrl_num_params = h->ctrl_num_params;
+    p.ctrl_hidden     = h->ctrl_hidden;
+    p.trk             = h->tracker;
+    p.trk_kind        = h->tracker_kind;
     p.cl_start  = h->cl_dirty ? nullptr : h->d_cl_start;
     p.cl_idx    = h->cl_dirty ? nullptr : h->d_cl_idx;
     if (h->episode)
@@ -708,6 +713,18 @@ int launchStep(okenv *h, OkStepParams p) // (by value: the diagnostic build adds
             const uint32_t off = static_cast<uint32_t>(h->image_bytes);
             if (p.action_source == kActionsQLearning)
                 hipLaunchKernelGGL(okStepCoopKernel<kPolicyQ>, grid, block, lds + qLdsBytes(h), h->stream, p, off, phase1);
+            else if (p.action_source == kActionsController)
+            { // the controllers' parameters of a workgroup's agents go into its LDS when they fit behind the centre line
+                const size_t base  = ((lds + qLdsBytes(h) + 15U) / 16U) * 16U;
+                const size_t stage = static_cast<size_t>(block.x / static_cast<unsigned>(p.G)) * static_cast<size_t>(h->ctrl_num_params) * sizeof(float);
+                size_t       total = lds + qLdsBytes(h);
+                if (base + stage <= kLdsBudget)
+                {
+                    p.ctrl_lds_off = static_cast<uint32_t>(base);
+                    total          = base + stage;
+                }
+                hipLaunchKernelGGL(okStepCoopKernel<kPolicyCtrl>, grid, block, total, h->stream, p, off, phase1);
+            }
             else if (policy == kPolicyMlp && h->G == 32 && h->R == 32) // C3 / C4's fan: group and fan width compile-time constants
                 hipLaunchKernelGGL((okStepCoopKernel<kPolicyMlp, false, false, false, 32>), grid, block, lds, h->stream, p, off, h->phase1_range);
             else if (policy == kPolicyMlp)
@@ -896,6 +913,8 @@ extern "C"
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyMlp>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyQ>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyCtrl>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyMlp, false, false, false, 32>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
@@ -1675,13 +1694,12 @@ extern "C"
         if (h->P <= 0)
             return fail(h, OKENV_ERR_STATE, "okenv_tracker_create: call okenv_set_centerline first");
         OK_HIP(h, hipSetDevice(h->device));
-        if (!h->tracker.fitness)
         {
             const size_t N = static_cast<size_t>(h->N);
             int          rc;
-            if ((rc = devAlloc(h, &h->tracker.prev_idx, N)) || (rc = devAlloc(h, &h->tracker.fitness, N)) ||
-                (rc = devAlloc(h, &h->tracker.reward, N)) || (rc = devAlloc(h, &h->tracker.ep_steps, N)) ||
-                (rc = devAlloc(h, &h->tracker.ep_return, N)) || (rc = devAlloc(h, &h->tracker.prev_crashed, N)))
+            if ((rc = devEnsure(h, &h->tracker.prev_idx, N)) || (rc = devEnsure(h, &h->tracker.fitness, N)) ||
+                (rc = devEnsure(h, &h->tracker.reward, N)) || (rc = devEnsure(h, &h->tracker.ep_steps, N)) ||
+                (rc = devEnsure(h, &h->tracker.ep_return, N)) || (rc = devEnsure(h, &h->tracker.prev_crashed, N)))
                 return rc;
         }
         h->tracker_kind = reward_kind;
@@ -1777,6 +1795,54 @@ extern "C"
         return OKENV_OK;
     }
 
+    int okenv_rollout_controller(okenv_t h, int32_t n_steps, float throttle, float steering_scale)
+    {
+        OK_QUIESCE(h);
+        if (!h || n_steps < 0)
+            return fail(h, OKENV_ERR_INVALID, "okenv_rollout_controller: bad argument");
+        if (!h->d_ctrl_params)
+            return fail(h, OKENV_ERR_STATE, "okenv_rollout_controller: call okenv_controller_create first");
+        if (h->tracker_kind < 0)
+            return fail(h, OKENV_ERR_STATE, "okenv_rollout_controller: call okenv_tracker_create first");
+        if (h->grid_mode != kGridLds || !h->coop || h->rays_per_lane != 1 || h->G < 8)
+            return fail(h, OKENV_ERR_STATE, "okenv_rollout_controller: needs the LDS form of the step kernel with at most 64 rays "
+                                            "(use okenv_controller_act + okenv_step + okenv_tracker_update)");
+        if (h->ctrl_hidden > kCtrlUnitsPerLane * h->G)
+            return fail(h, OKENV_ERR_STATE, "okenv_rollout_controller: the hidden layer is too wide for this fan's lane groups (hidden <= 4 x lanes per agent); "
+                                            "use okenv_controller_act + okenv_step + okenv_tracker_update");
+        if (coopLdsBytes(h) + qLdsBytes(h) > kLdsBudget)
+            return fail(h, OKENV_ERR_STATE, "okenv_rollout_controller: track image + centre line do not fit the CU's LDS");
+        if (n_steps == 0)
+            return OKENV_OK;
+        OK_HIP(h, hipSetDevice(h->device));
+        const int brc = buildCenterlineBuckets(h);
+        if (brc != OKENV_OK)
+            return brc;
+        if (h->episode)
+        {
+            if (h->ep_kind != 0 && h->ep_kind != kPolicyCtrl)
+                return fail(h, OKENV_ERR_STATE, "okenv_rollout_controller: the running episode belongs to another rollout (okenv_rollout_policy / _q)");
+            if ((h->reset_flags & kAutoResetOn) != 0U)
+                return fail(h, OKENV_ERR_STATE, "okenv_rollout_controller: episodes need auto-reset off");
+            // (an episode stops stepping an agent once it has crashed and taken one more step; the +1-per-step reward keeps counting
+            // for crashed agents, so its bookkeeping would fall behind the per-step loop's)
+            if (h->tracker_kind != kRewardProgress)
+                return fail(h, OKENV_ERR_STATE, "okenv_rollout_controller: inside an episode the bookkeeping must be OKENV_REWARD_PROGRESS");
+            h->ep_kind = kPolicyCtrl;
+        }
+        OkStepParams p     = baseParams(h);
+        p.n_steps          = n_steps;
+        p.action_source    = kActionsController;
+        p.ctrl_throttle    = throttle;
+        p.ctrl_steer_scale = steering_scale;
+        int rc             = OKENV_OK;
+        if (!(h->episode && h->n_active == 0)) // (nobody left to step: the steps still count)
+            rc = launchStep(h, p);
+        if (rc == OKENV_OK && h->episode)
+            h->ep_steps += static_cast<uint32_t>(n_steps);
+        return rc == OKENV_OK ? advanceStepCount(h, n_steps) : rc;
+    }
+
     // ---- EvolutionaryRacer ---------------------------------------------------------------------------------------
 
     int okenv_policy_mlp_create(okenv_t h, int32_t hidden, uint32_t seed, uint32_t agent_base)
@@ -1844,7 +1910,7 @@ extern "C"
         if (h->episode)
         {
             if (h->ep_kind != 0 && h->ep_kind != kPolicyMlp)
-                return fail(h, OKENV_ERR_STATE, "okenv_rollout_policy: the running episode belongs to okenv_rollout_q");
+                return fail(h, OKENV_ERR_STATE, "okenv_rollout_policy: the running episode belongs to another rollout (okenv_rollout_q / _controller)");
             if ((h->reset_flags & kAutoResetOn) != 0U)
                 return fail(h, OKENV_ERR_STATE, "okenv_rollout_policy: episodes need auto-reset off");
             h->ep_kind = kPolicyMlp;
@@ -1908,8 +1974,9 @@ extern "C"
         OK_QUIESCE(h);
         if (!h || !out)
             return fail(h, OKENV_ERR_INVALID, "okenv_episode_tail_limit: NULL argument");
-        const bool q = h->ep_kind == kPolicyQ || (h->ep_kind == 0 && h->d_q_table != nullptr && h->d_mlp_w == nullptr);
-        *out         = static_cast<int32_t>(tailLimit(h, q));
+        const bool q    = h->ep_kind == kPolicyQ || (h->ep_kind == 0 && h->d_q_table != nullptr && h->d_mlp_w == nullptr);
+        const bool ctrl = h->ep_kind == kPolicyCtrl || (h->ep_kind == 0 && h->d_ctrl_params != nullptr && h->d_mlp_w == nullptr && h->d_q_table == nullptr);
+        *out            = ctrl ? 0 : static_cast<int32_t>(tailLimit(h, q)); // (the controller rollout has no one-agent-per-workgroup form)
         return OKENV_OK;
     }
 
@@ -1921,7 +1988,7 @@ extern "C"
         OK_HIP(h, hipSetDevice(h->device));
         const unsigned blocks = static_cast<unsigned>((h->N + 255) / 256);
         hipLaunchKernelGGL(okEpisodeEndKernel, dim3(1), dim3(1024), 0, h->stream, h->st.crashed, h->d_crash_step, h->N, h->ep_steps, h->d_ep_out);
-        if (h->ep_kind == kPolicyMlp)
+        if (h->ep_kind == kPolicyMlp || h->ep_kind == kPolicyCtrl)
             hipLaunchKernelGGL(okEpisodeFixupKernel, dim3(blocks), dim3(256), 0, h->stream, h->st, h->d_crash_step, h->d_crash_thr, h->d_crash_steer,
                                h->d_ep_out, h->N);
         else if (h->ep_kind == kPolicyQ)
@@ -1936,7 +2003,7 @@ extern "C"
         OK_HIP(h, hipMemcpyAsync(&live, h->d_live, sizeof(live), hipMemcpyDeviceToHost, h->stream));
         OK_HIP(h, hipStreamSynchronize(h->stream));
         // the steps beyond T were taken by nobody who could still move: they do not count
-        if (h->ep_kind == kPolicyMlp)
+        if (h->ep_kind == kPolicyMlp || h->ep_kind == kPolicyCtrl)
             h->step_count -= h->ep_steps - out[0];
         if (steps_out)
             *steps_out = static_cast<int32_t>(out[0]);
@@ -2115,7 +2182,7 @@ extern "C"
         if (h->episode)
         {
             if (h->ep_kind != 0 && h->ep_kind != kPolicyQ)
-                return fail(h, OKENV_ERR_STATE, "okenv_rollout_q: the running episode belongs to okenv_rollout_policy");
+                return fail(h, OKENV_ERR_STATE, "okenv_rollout_q: the running episode belongs to another rollout (okenv_rollout_policy / _controller)");
             if (h->ep_kind == 0)
             {
                 h->ep_kind         = kPolicyQ;

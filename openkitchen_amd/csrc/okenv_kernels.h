@@ -52,6 +52,24 @@ enum OkActionSource : int
     kActionsPhiloxReset = 1, // bench recipe: per step reset crashed agents, draw U[0,100) x U[-5,5)
     kActionsMlpPolicy   = 2, // EvolutionaryRacer: per step GeneticAgent::updateAction from the previous observation
     kActionsQLearning   = 3, // RLRacers/Q_Learning: epsilon-greedy action before the step, reward + table update after it
+    kActionsController  = 4, // CMA-ES racers: per step CmaEsAgent::updateAction from the previous observation, fitness bookkeeping after it
+};
+
+// Rollout bookkeeping of the current-API callers (okenv_tracker_*)
+struct OkTracker
+{
+    int32_t  *prev_idx;     // prev_track_idx_
+    float    *fitness;      // fitness_ / running return
+    float    *reward;       // of the last update
+    uint32_t *ep_steps;
+    float    *ep_return;    // fitness when the last episode ended
+    uint8_t  *prev_crashed; // crashed_ as of the previous update
+};
+
+enum OkRewardKind : int
+{
+    kRewardStep     = 0, // ppo_sim.cpp:77-80
+    kRewardProgress = 1, // main_eigen.cpp:147-158
 };
 
 struct OkStepParams
@@ -98,6 +116,15 @@ struct OkStepParams
     const uint16_t *cl_start, *cl_idx;
     int      q_ray[5];
     float    q_epsilon;
+    // CMA-ES racers (okenv_rollout_controller): the candidates' controller parameters [N][ctrl_num_params] (Controller.cpp's
+    // parameters() order), the constant throttle and the steering scale of CmaEsAgent::updateAction, and the bookkeeping the
+    // callers run after env.step() (okenv_tracker_*), all inside the step kernel
+    const float *ctrl_params;
+    int          ctrl_num_params, ctrl_hidden;
+    float        ctrl_throttle, ctrl_steer_scale;
+    OkTracker    trk;
+    int          trk_kind;
+    uint32_t     ctrl_lds_off; // byte offset in the workgroup's LDS where its agents' parameters are staged for the launch (0: read from global memory)
     // Packed host exchange (okenv_step_packed, the C++ facade's Environment::step): when set, the step kernel takes the
     // agents' state from `rec_in` and leaves state and sensor_hits_ (x, y pairs) in `rec_out` / `hits_xy_out`, all three in
     // host memory mapped into the device, so that a facade step is ONE kernel with no staging copies around it.
@@ -164,6 +191,7 @@ enum OkPolicyKind : int
     kPolicyNone = 0, // actions stored by the host, or the bench driver's Philox actions
     kPolicyMlp  = 1, // EvolutionaryRacer
     kPolicyQ    = 2, // RLRacers/Q_Learning
+    kPolicyCtrl = 3, // CMA-ES racers: controller before the step, fitness bookkeeping after it
 };
 
 enum OkGridMode : int
@@ -684,6 +712,132 @@ okPolicyAction(const OkStepParams &p, const int a, const int rlane, const int G,
         okMlpAction<4>(p, a, rlane, G, ag, dist_self, ray_ok); // G == 8 (the C ABI refuses narrower fans)
 }
 
+// ---- CMA-ES racers' pieces of the fused rollout (okenv_rollout_controller) -----------------------------------------------
+
+// CmaEsAgent::updateAction (CovarianceMatrixAdaptationEvolution/main_eigen.cpp:45-68, Controller.cpp:3-23) by the G lanes of the
+// agent's group: tanh(fc3(tanh(fc2(tanh(fc1(x)))))), x = the agent's distances / kSensorRange (ray i's in lane i), fc1: R ->
+// hidden, fc2: hidden -> hidden / 2, fc3: hidden / 2 -> 2 (only output 0 is used: steering; the throttle is a constant).  Lane r
+// evaluates units r, r + G, ... of a layer; the previous layer's outputs come by shuffles; every sum starts from the bias and adds
+// w * x in ascending input order (fp32, no FMA) -- the same terms in the same order as okControllerKernel and the oracle's
+// ctrl_forward, whatever G.  At most kCtrlUnitsPerLane units of a layer per lane (hidden <= 4 G; the host checks it): with eight the
+// kernel needs scratch.
+constexpr int kCtrlUnitsPerLane = 4;
+
+// One layer: out[q] = B[u] + sum over i of W[u * n_in + i] * input i, for the lane's units u = r + q * G < n_out; input i sits in
+// lane i % G, register in[i / G].  Ascending i, one multiply and one add per term.
+// kCtrlBatch: inputs whose weights are fetched together (the loads of a batch are in flight at once)
+template <int kCtrlBatch, int kIn, int kOut>
+__device__ __forceinline__ void
+okCtrlLayer(float (&out)[kOut], const float (&in)[kIn], const float *W, const float *B, const int n_in, const int n_out, const int r, const int G)
+{
+#pragma unroll
+    for (int q = 0; q < kOut; ++q)
+    {
+        const int u = r + q * G;
+        out[q]      = (u < n_out) ? B[u] : 0.F;
+    }
+    const int g_shift = 31 - __builtin_clz(G);
+    for (int i0 = 0; i0 < n_in; i0 += kCtrlBatch)
+    {
+        float w[kOut][kCtrlBatch], xs[kCtrlBatch];
+#pragma unroll
+        for (int q = 0; q < kOut; ++q)
+        {
+            const int u = r + q * G;
+#pragma unroll
+            for (int j = 0; j < kCtrlBatch; ++j)
+                w[q][j] = (u < n_out && i0 + j < n_in) ? W[u * n_in + i0 + j] : 0.F;
+        }
+#pragma unroll
+        for (int j = 0; j < kCtrlBatch; ++j)
+        {
+            const int i   = i0 + j;
+            const int reg = i >> g_shift; // (the same in every lane)
+            float     v   = in[0];
+#pragma unroll
+            for (int k = 1; k < kIn; ++k)
+                v = (reg == k) ? in[k] : v;
+            xs[j] = __shfl(v, i & (G - 1), G);
+        }
+#pragma unroll
+        for (int j = 0; j < kCtrlBatch; ++j)
+        {
+            if (i0 + j < n_in)
+            {
+#pragma unroll
+                for (int q = 0; q < kOut; ++q)
+                    if (r + q * G < n_out)
+                        out[q] = out[q] + w[q][j] * xs[j];
+            }
+        }
+    }
+}
+
+// kUnits: units of a layer a lane may have to evaluate (1 when hidden <= G, the usual case: bigger batches fit the registers then)
+template <int kCtrlBatch, int kUnits>
+__device__ __forceinline__ void okCtrlAction(const OkStepParams &p, const float *prm, const int r, const int G, OkAgentRegs &ag, const float dist_self)
+{
+    const int    R = p.R, H = p.ctrl_hidden, H2 = H / 2;
+    const float *w1 = prm, *b1 = w1 + H * R, *w2 = b1 + H, *b2 = w2 + H2 * H, *w3 = b2 + H2, *b3 = w3 + 2 * H2;
+    const float  x[1] = {dist_self / OK_SENSOR_RANGE};
+    constexpr int kUnits2 = kUnits > 1 ? kUnits / 2 : 1;
+    float         a1[kUnits], a2[kUnits2], a3[1];
+    okCtrlLayer<kCtrlBatch>(a1, x, w1, b1, R, H, r, G);
+#pragma unroll
+    for (int q = 0; q < kUnits; ++q)
+        a1[q] = (r + q * G < H) ? ok_tanhf(a1[q]) : 0.F;
+    okCtrlLayer<kCtrlBatch>(a2, a1, w2, b2, H, H2, r, G);
+#pragma unroll
+    for (int q = 0; q < kUnits2; ++q)
+        a2[q] = (r + q * G < H2) ? ok_tanhf(a2[q]) : 0.F;
+    okCtrlLayer<kCtrlBatch>(a3, a2, w3, b3, H2, 1, r, G); // output 0 (steering), by lane 0
+    ag.thr   = p.ctrl_throttle;
+    ag.steer = __shfl(ok_tanhf(a3[0]) * p.ctrl_steer_scale, 0, G);
+}
+
+// okTrackerKernel's update (begin == 0) on values carried in registers: the callers' loop body after env.step()
+// (main_eigen.cpp:143-158, ppo_sim.cpp:77-80); `idx` is the nearest centre-line index of the new position (PROGRESS only).
+struct OkTrackerRegs
+{
+    int      prev_idx;
+    float    fitness, reward, ep_return;
+    uint32_t ep_steps;
+    bool     prev_crashed;
+};
+
+__device__ __forceinline__ void okTrackerStep(OkTrackerRegs &t, const int kind, const int idx, const bool crashed, const bool timed_out)
+{
+    float reward = 0.F;
+    if (t.prev_crashed && !crashed)
+    { // re-placed since the last update: this step was the new episode's initial observation
+        t.fitness  = 0.F;
+        t.ep_steps = 0U;
+        t.prev_idx = idx;
+    }
+    else if (kind == kRewardStep)
+    {
+        reward = 1.F;
+        t.fitness += 1.F;
+        t.ep_steps += 1U;
+    }
+    else if (!crashed)
+    {
+        const int progress = idx - t.prev_idx;
+        t.prev_idx         = idx;
+        reward             = static_cast<float>(progress < 0 ? -progress : progress);
+        t.fitness += reward;
+        t.ep_steps += 1U;
+    }
+    else if (timed_out)
+    {
+        t.fitness = 0.F;
+    }
+    t.reward = reward;
+    if (crashed && !t.prev_crashed)
+        t.ep_return = t.fitness;
+    t.prev_crashed = crashed;
+}
+
 template <int kMode>
 __device__ __forceinline__ OkPolyView okSetupView(const OkStepParams &p, unsigned char *lds)
 {
@@ -983,7 +1137,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
     float    *lds_cy     = lds_cx + p.P;
     uint16_t *lds_cstart = reinterpret_cast<uint16_t *>(lds_cy + p.P);
     uint16_t *lds_cidx   = lds_cstart + (p.geom.nx * p.geom.ny + 1);
-    if (kPolicy == kPolicyQ)
+    if (kPolicy == kPolicyQ || kPolicy == kPolicyCtrl)
     {
         for (int i = threadIdx.x; i < p.P; i += blockDim.x)
         {
@@ -1041,6 +1195,15 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
         ag = okLoadAgent(p.st, a);
         if (kPacked)
             rc_in = p.rec_in[a];
+    }
+    // CMA-ES racers: the group's controller parameters, read by every step of the launch, are staged behind the centre line when
+    // the workgroup's groups fit there (the host decides: ctrl_lds_off): an LDS round trip per batch of weights instead of an L2 one
+    if (kPolicy == kPolicyCtrl && p.ctrl_lds_off != 0U)
+    {
+        float       *s_ctrl = reinterpret_cast<float *>(ok_lds + p.ctrl_lds_off) + static_cast<size_t>(in_block) * p.ctrl_num_params;
+        const float *src    = p.ctrl_params + static_cast<size_t>(a) * p.ctrl_num_params;
+        for (int i = r; i < p.ctrl_num_params; i += G)
+            s_ctrl[i] = src[i];
     }
     const OkPolyView view = okSetupView<kGridLds>(p, ok_lds); // ends with a barrier
 #if OKENV_PRIO == 2
@@ -1122,6 +1285,16 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
             qs.prev   = p.q_prev_idx[a];
             q_row0    = p.q_table + static_cast<size_t>(a) * (OK_Q_STATES * OK_Q_ACTIONS);
         }
+        OkTrackerRegs trk{};
+        if (kPolicy == kPolicyCtrl)
+        { // the bookkeeping's state travels in registers for the launch (every lane of the group holds a copy, lane 0 stores it)
+            trk.prev_idx     = p.trk.prev_idx[a];
+            trk.fitness      = p.trk.fitness[a];
+            trk.reward       = p.trk.reward[a];
+            trk.ep_return    = p.trk.ep_return[a];
+            trk.ep_steps     = p.trk.ep_steps[a];
+            trk.prev_crashed = p.trk.prev_crashed[a] != 0;
+        }
         // Q values of the agent's current state.  The table (47.8 MB at C5) lives in HBM / Infinity Cache and only this
         // group ever touches this agent's part of it, so the row is read once per launch and then carried in registers:
         // after a step it is either patched with the value just learned or replaced by the next state's row, which the
@@ -1199,6 +1372,19 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                     okMlpActionWide<32>(p, a, r, G, ag, last_dist, ray_ok, mlp_col);
                 else
                     okPolicyAction(p, a, r, G, ag, last_dist, ray_ok);
+            }
+            if (kPolicy == kPolicyCtrl)
+            {
+                if (p.ctrl_lds_off != 0U) // (LDS: short round trips, small batches; the address is formed here, every step)
+                {
+                    const float *prm = reinterpret_cast<const float *>(ok_lds + p.ctrl_lds_off) + static_cast<size_t>(okOpaque(in_block)) * p.ctrl_num_params;
+                    if (p.ctrl_hidden <= G)
+                        okCtrlAction<8, 1>(p, prm, r, G, ag, last_dist);
+                    else
+                        okCtrlAction<2, kCtrlUnitsPerLane>(p, prm, r, G, ag, last_dist);
+                }
+                else
+                    okCtrlAction<4, kCtrlUnitsPerLane>(p, p.ctrl_params + static_cast<size_t>(okOpaque(a)) * p.ctrl_num_params, r, G, ag, last_dist);
             }
             if (kPolicy == kPolicyQ && !q_frozen)
             { // QLearnAgent::updateAction (QAgent.hpp:98-119) from the carried row of the current state
@@ -1402,6 +1588,13 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                         p.q_next_state[okOpaque(a)] = next_state; // what every later step of this agent will see as its next state
                 }
             }
+            if (kPolicy == kPolicyCtrl)
+            { // the callers' bookkeeping after env.step() (main_eigen.cpp:143-158 / ppo_sim.cpp:77-80)
+                int idx = 0;
+                if (p.trk_kind == kRewardProgress)
+                    idx = okNearestBucketed(p, lds_cx, lds_cy, lds_cstart, lds_cidx, ag.pos_x, ag.pos_y, r, G);
+                okTrackerStep(trk, p.trk_kind, idx, ag.crashed, ag.timed_out);
+            }
             if (episode)
             {
                 if (was_crashed)
@@ -1425,6 +1618,16 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
             p.settled[okOpaque(a)] = settled ? 1 : 0;
             if (live_n != 0U)
                 atomicAdd(p.live, static_cast<unsigned long long>(live_n));
+        }
+        if (kPolicy == kPolicyCtrl && agent_ok && r == 0 && n_steps > 0)
+        {
+            const int ae            = okOpaque(a);
+            p.trk.prev_idx[ae]      = trk.prev_idx;
+            p.trk.fitness[ae]       = trk.fitness;
+            p.trk.reward[ae]        = trk.reward;
+            p.trk.ep_return[ae]     = trk.ep_return;
+            p.trk.ep_steps[ae]      = trk.ep_steps;
+            p.trk.prev_crashed[ae]  = trk.prev_crashed ? 1 : 0;
         }
         if (kPolicy == kPolicyQ && agent_ok && r == 0)
         {
@@ -2078,22 +2281,6 @@ __global__ void okControllerKernel(OkDeviceState st, const float *params, int nu
 }
 
 // ---- rollout bookkeeping ------------------------------------------------------------
-
-struct OkTracker
-{
-    int32_t  *prev_idx;     // prev_track_idx_
-    float    *fitness;      // fitness_ / running return
-    float    *reward;       // of the last update
-    uint32_t *ep_steps;
-    float    *ep_return;    // fitness when the last episode ended
-    uint8_t  *prev_crashed; // crashed_ as of the previous update
-};
-
-enum OkRewardKind : int
-{
-    kRewardStep     = 0, // ppo_sim.cpp:77-80
-    kRewardProgress = 1, // main_eigen.cpp:147-158
-};
 
 // The callers' loop body after env.step() (begin != 0: the episode start of main_eigen.cpp:128-133).  kNearestLanes
 // lanes per agent for the index-progress reward (they share the nearest-index scan, the first lane does the

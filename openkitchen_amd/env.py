@@ -223,6 +223,10 @@ class BatchedEnvironment:
         """CmaEsAgent::updateAction for every agent (main_eigen.cpp:58-68)."""
         capi.check(self._L.okenv_controller_act(self._h, float(throttle), float(steering_scale)), self._h)
 
+    def rollout_controller(self, n_steps, throttle=100.0, steering_scale=5.0):
+        """n_steps iterations of the CMA-ES racers' inner loop (controller, Environment::step, fitness bookkeeping) in one launch."""
+        capi.check(self._L.okenv_rollout_controller(self._h, int(n_steps), float(throttle), float(steering_scale)), self._h)
+
     def tracker_snapshot(self):
         return {capi.FIELD_NAMES[f]: self.get(f) for f in range(capi.F_REWARD, capi.F_EPISODE_RETURN + 1)}
 

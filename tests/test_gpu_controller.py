@@ -70,14 +70,15 @@ def test_controller_close_to_the_torch_module(gpu, oracle):
     dev.close()
 
 
-def test_cmaes_generation_against_the_oracle_running_the_same_controllers(gpu, oracle):
+@pytest.mark.parametrize("rollout", [False, True])
+def test_cmaes_generation_against_the_oracle_running_the_same_controllers(gpu, oracle, rollout):
     """main_eigen.cpp:113-171 for 96 candidates: the device runs controller -> Environment::step -> fitness bookkeeping as a
-    replayed HIP graph; the oracle runs the same loop with its own controller, step and bookkeeping.  Fitness and flags
-    agree bit for bit."""
+    replayed HIP graph of the three calls (rollout=False) or fused into the step kernel as an episode (rollout=True); the oracle
+    runs the same loop with its own controller, step and bookkeeping.  Fitness and flags agree bit for bit."""
     from openkitchen_amd.cmaes import CmaEsRacers
     N = 96
-    racers = CmaEsRacers("Austin", N, seed=3, max_steps=640)
-    assert racers.fused
+    racers = CmaEsRacers("Austin", N, seed=3, max_steps=640, rollout=rollout)
+    assert racers.fused and racers.rollout == rollout
     seen, inner = [], racers.set_params
 
     def spy(population):

@@ -67,7 +67,7 @@ def test_tracker_bit_exact(gpu, oracle, kind, auto_reset):
 def test_cmaes_generation_fitness_matches_oracle_replay(gpu, oracle):
     from openkitchen_amd.cmaes import CmaEsRacers
     N = 96
-    racers = CmaEsRacers("Austin", N, seed=3, max_steps=900)
+    racers = CmaEsRacers("Austin", N, seed=3, max_steps=900, rollout=False)  # the three calls per iteration: env.step is visible
     venv, log = racers.venv, []
     inner = venv.step
 
@@ -110,14 +110,19 @@ def test_cmaes_graph_replay_equals_eager(gpu):
     """The captured iteration (controller forward + env.step + bookkeeping) gives the same fitness as eager launches,
     generation after generation; capturing has no side effect on the simulation state."""
     from openkitchen_amd.cmaes import CmaEsRacers
-    a = CmaEsRacers("Monza", 64, seed=11, max_steps=500)
-    b = CmaEsRacers("Monza", 64, seed=11, max_steps=500)
+    a = CmaEsRacers("Monza", 64, seed=11, max_steps=500, rollout=False)
+    b = CmaEsRacers("Monza", 64, seed=11, max_steps=500, rollout=False)
+    c = CmaEsRacers("Monza", 64, seed=11, max_steps=500)  # the fused rollout, as an episode
     for g in range(3):
         ba, sa = a.run_generation(use_graph=False)
         bb, sb = b.run_generation(use_graph=True)
+        bc, sc = c.run_generation()
         assert (ba, sa) == (bb, sb), g
         assert np.array_equal(a.venv.fitness.cpu().numpy(), b.venv.fitness.cpu().numpy()), g
         assert np.array_equal(a.venv.disp_ctr.cpu().numpy(), b.venv.disp_ctr.cpu().numpy()), g
+        # ... and as the fused rollout: the same fitness (hence the same next population), the loop's exact length
+        assert bc == ba and sa - 16 < sc <= sa, (g, sa, sc)
+        assert np.array_equal(a.venv.fitness.cpu().numpy(), c.venv.fitness.cpu().numpy()), g
 
 
 def test_collect_episode_shapes_and_semantics(gpu):

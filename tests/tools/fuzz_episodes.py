@@ -36,9 +36,10 @@ t0, cases, steps_total = time.time(), 0, 0
 while time.time() - t0 < budget:
     name = str(rng.choice(list(tracks)))
     t = tracks[name]
-    kind = "q" if rng.random() < 0.45 else "ga"
+    u = rng.random()
+    kind = "q" if u < 0.35 else ("ctrl" if u < 0.55 else "ga")
     N = int(rng.choice([2, 9, 40, 100, 260, 420]))
-    R = int(rng.choice([5, 8, 15, 16, 32] if kind == "q" else [5, 8, 15, 16, 31, 32, 64]))
+    R = int(rng.choice([5, 8, 15, 16, 32] if kind == "q" else ([5, 9, 16, 33, 64] if kind == "ctrl" else [5, 8, 15, 16, 31, 32, 64])))
     fan = ok.default_ray_fan(R)
     spl = int(rng.choice([1, 3, 17, 50, 100, 333]))
     cap = int(rng.choice([40, 300, 1200]))
@@ -88,6 +89,52 @@ while time.time() - t0 < budget:
             same(dev.snapshot(), orc.snapshot(), what)
             if not np.array_equal(dev.ga_select_mate(seed, generation), ga.select_mate(seed, generation)):
                 print("MISMATCH parents: " + what, flush=True); sys.exit(1)
+            steps_total += it
+    elif kind == "ctrl":
+        # the CMA-ES racers' loop (main_eigen.cpp:135-160): controller, Environment::step, fitness bookkeeping, fused (okenv_rollout_controller)
+        G = dev.info()["lanes_per_agent"]
+        hidden = int(rng.choice([h for h in (2, 6, 16, 32, 64) if h <= 4 * G]))
+        rk = int(rng.integers(0, 2))
+        n_params = dev.controller_create(hidden)
+        for generation in range(2):
+            idx = rng.integers(0, t.P, N)
+            for e in (dev, orc):
+                e.reset_agents(np.arange(N), t.x[idx], t.y[idx], t.heading[idx])
+            if pre_crashed is not None:
+                dev.set(ok.capi.F_CRASHED, pre_crashed); orc.set(O.F_CRASHED, pre_crashed)
+            dev.step(1); orc.step(1)
+            params = rng.normal(0, float(rng.choice([0.3, 1.0])), (N, n_params)).astype(np.float32)
+            dev.controller_set_params(params)
+            for e in (dev, orc):
+                e.tracker_create(rk); e.tracker_begin()
+            it, live = 0, 0
+            while it < cap:
+                live += O.lib().oracle_env_alive_count(orc.h)
+                O.lib().oracle_env_controller_act(orc.h, params, hidden, 100.0, 5.0); orc.step(1); orc.tracker_update(); it += 1
+                if O.lib().oracle_env_alive_count(orc.h) == 0:
+                    break
+            if rk == 1:
+                dev.episode_begin()
+                taken = 0
+                while taken < cap:
+                    n = min(spl, cap - taken)
+                    dev.rollout_controller(n, 100.0, 5.0); taken += n
+                    alive, listed = dev.episode_compact()
+                    if alive == 0:
+                        break
+                steps, dlive = dev.episode_end()
+                if (steps, dlive) != (it, live):
+                    print("MISMATCH steps/live %s vs oracle %s: %s" % ((steps, dlive), (it, live), what), flush=True); sys.exit(1)
+            else:  # the +1-per-step reward counts for crashed agents too: no episode, launches of any length up to the loop's own
+                taken = 0
+                while taken < it:
+                    n = min(spl, it - taken)
+                    dev.rollout_controller(n, 100.0, 5.0); taken += n
+            same(dev.snapshot(), orc.snapshot(), what + " hidden=%d reward=%d" % (hidden, rk))
+            d, o = dev.tracker_snapshot(), orc.tracker_snapshot()
+            for k in o:
+                if not np.array_equal(np.ascontiguousarray(d[k]).view(np.uint32), np.ascontiguousarray(o[k]).view(np.uint32)):
+                    print("MISMATCH tracker %s: %s hidden=%d reward=%d" % (k, what, hidden, rk), flush=True); sys.exit(1)
             steps_total += it
     else:
         dev.q_create(); oq = O.OracleQ(orc)

@@ -63,6 +63,29 @@ def c5(N, spl=50, lanes=None):
     report("c5 N=%d G=%d alive %d" % (N, env.info()["lanes_per_agent"], env.alive_count()), env, spl, ms)
     env.close()
 
+def ctrl(N, spl=50, lanes=None):
+    """The CMA-ES racers' fused rollout: five rays, controller 5-16-8-2, index-progress fitness."""
+    if lanes:
+        os.environ["OKENV_LANES_PER_AGENT"] = str(lanes)
+    else:
+        os.environ.pop("OKENV_LANES_PER_AGENT", None)
+    t = ok.Track("Silverstone")
+    fan = np.array([-70, -30, 0, 30, 70], dtype=np.float32)
+    env = ok.BatchedEnvironment.from_track(t, N, ray_angles_deg=fan)
+    rng = np.random.default_rng(1)
+    idx = rng.integers(0, t.P, N)
+    env.reset_agents(np.arange(N), t.x[idx], t.y[idx], t.heading[idx])
+    env.step(1)
+    n_params = env.controller_create(16)
+    env.controller_set_params(rng.normal(0, 0.5, (N, n_params)).astype(np.float32))
+    env.tracker_create(1); env.tracker_begin()
+    env.rollout_controller(20); env.sync()
+    env.set_timing(True)
+    env.rollout_controller(spl)
+    ms, n = env.get_timing()
+    report("ctrl N=%d G=%d alive %d" % (N, env.info()["lanes_per_agent"], env.alive_count()), env, spl, ms)
+    env.close()
+
 def setp1(v):
     if v is None:
         os.environ.pop("OKENV_PHASE1_RANGE", None)
@@ -74,7 +97,7 @@ if len(sys.argv) > 1:  # e.g. c3:16:64:48 c5:256:64:0  (config:agents:lanes per 
         cfg, N, lanes, p1 = spec.split(":")
         setp1(None if p1 == "-" else p1)
         print("[%s]" % spec, end=" ")
-        (c3 if cfg == "c3" else c5)(int(N), lanes=None if lanes == "-" else int(lanes))
+        {"c3": c3, "c5": c5, "ctrl": ctrl}[cfg](int(N), lanes=None if lanes == "-" else int(lanes))
 else:
     for N, lanes in ((8192, None), (256, 32), (256, 64), (16, 32), (16, 64)):
         c3(N, lanes=lanes)
