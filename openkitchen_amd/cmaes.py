@@ -80,22 +80,32 @@ class CmaEsSolver:
     def tell(self, solutions, fitness):
         """Higher fitness is better (the reference sorts descending, CmaEsSolverEigen.cpp:86-90)."""
         order = np.argsort(-np.asarray(fitness, dtype=np.float64), kind="stable")[: self.num_parents]
-        if torch.is_tensor(solutions):  # only the parents travel to the host
-            parents = solutions[torch.as_tensor(order, device=solutions.device)].to(torch.float64).cpu().numpy()
+        if torch.is_tensor(solutions):
+            # the two products over the parents (the weighted mean and the rank-mu matrix: with thousands of candidates the bulk of
+            # the update's arithmetic) are formed where the candidates live, in float64; the mean and an n x n matrix travel to the host
+            f64 = dict(dtype=torch.float64, device=solutions.device)
+            parents = solutions[torch.as_tensor(order, device=solutions.device)].to(torch.float64)
+            w = torch.as_tensor(self.weights, **f64)
+            mean = w @ parents
+            y = (parents - torch.as_tensor(self.mean, **f64)) / self.sigma
+            rank_mu = (y * w[:, None]).T @ y
+            mean, rank_mu = mean.cpu().numpy(), rank_mu.cpu().numpy()
         else:
             parents = np.asarray(solutions, dtype=np.float64)[order]
+            with _few_blas_threads():
+                mean = self.weights @ parents
+                y = (parents - self.mean) / self.sigma
+                rank_mu = (y * self.weights[:, None]).T @ y
         with _few_blas_threads():
-            self._update(parents)
+            self._update(mean, rank_mu)
 
-    def _update(self, parents):
+    def _update(self, mean, rank_mu):
         old_mean = self.mean
-        self.mean = self.weights @ parents
+        self.mean = mean
         y_w = (self.mean - old_mean) / self.sigma
         inv_sqrt_c = (self.B / self.D) @ self.B.T
         self.p_sigma = (1.0 - self.c_sigma) * self.p_sigma + np.sqrt(self.c_sigma * (2.0 - self.c_sigma) * self.mu_eff) * (inv_sqrt_c @ y_w)
         self.p_c = (1.0 - self.c_c) * self.p_c + np.sqrt(self.c_c * (2.0 - self.c_c) * self.mu_eff) * y_w
-        y = (parents - old_mean) / self.sigma
-        rank_mu = (y * self.weights[:, None]).T @ y
         self.C = (1.0 - self.c_1 - self.c_mu) * self.C + self.c_1 * np.outer(self.p_c, self.p_c) + self.c_mu * rank_mu
         self.sigma *= np.exp((self.c_sigma / self.d_sigma) * (np.linalg.norm(self.p_sigma) / self.chi_n - 1.0))
 
