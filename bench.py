@@ -78,44 +78,48 @@ C3_BYTES_STATE = 44.0 + 36.0  # agent state read + written
 
 
 def bench_secondary_configs(args, ok, torch, local_rank, log):
-    """BASELINE configs 3 and 5 inside the default run (rank 0, N=1): one warm + two timed EvolutionaryRacer generations on
-    Monza (8192 x 32 rays, fused MLP policy) and one warm + two timed Q-learning episodes on Silverstone (16384 x 16 rays).
+    """BASELINE configs 3, 4 (one island) and 5 inside the default run (rank 0, N=1): one warm + two timed EvolutionaryRacer
+    generations on Monza and on Spa (8192 x 32 rays, fused MLP policy) and one warm + two timed Q-learning episodes on Silverstone
+    (16384 x 16 rays).
     `value` counts agents x steps of the reference's loop (every agent is in the loop until the last one has crashed);
     `live_value` counts only the agent-steps of agents that entered the step alive -- the ones that move, cast rays and read
     their policy's weights."""
     from openkitchen_amd.evolution import EvolutionaryRacer
     from openkitchen_amd.qlearning import QLearningRacers
     out = {}
-    # ---- C3 ----
-    N, R = 8192, 32
-    track = ok.Track("Monza")
-    env = ok.BatchedEnvironment.from_track(track, N, R, device=local_rank)
-    ga = EvolutionaryRacer(env, track, hidden=30, seed=args.seed, agent_base=0, max_steps=4000, steps_per_launch=args.steps_per_launch,
-                           device=torch.device("cuda", local_rank))
-    ga.run_generation()
-    env.sync()
-    env.set_timing(True)
-    t0 = time.perf_counter()
-    recs = [ga.run_generation() for _ in range(2)]
-    env.sync()
-    dt = time.perf_counter() - t0
-    kernel_ms, launches = env.get_timing()
-    env.set_timing(False)
-    steps = sum(r["steps"] for r in recs)
-    live = sum(r["live_agent_steps"] for r in recs)
-    b_alg = C3_BYTES_STATE + 4.0 * R + 16.0 * track.S / N
-    b_w = 4.0 * ((R + 2) * 30 + 30 * 6)  # the agent's 1200 policy weights, read once per live agent-step when not cached
-    out["c3"] = {
-        "value": N * steps / dt, "live_value": live / dt, "unit": "agent-steps/s", "ms_per_step": dt / steps * 1e3,
-        "generation_ms": [1e3 * (r["rollout_s"] + r["select_mate_s"]) for r in recs], "steps": [r["steps"] for r in recs],
-        "live_fraction": live / float(N * steps), "kernel_ms_step_launches": kernel_ms, "launches": int(launches),
-        "workload": "C3: EvolutionaryRacer, %d agents x %d rays, Monza.csv, fused 34-30-6 MLP policy + Environment::step, rollout until all "
-                    "crashed, score, select top-5, mate; 2 generations after 1 warm-up" % (N, R),
-        "roofline": {"bound": "hbm", "algorithmic_bytes_per_agent_step": b_alg + b_w, "of_which_policy_weights": b_w,
-                     "achieved": (b_alg + b_w) * live / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (b_alg + b_w) * live / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else None,
-                     "note": "bytes of LIVE agent-steps (crashed agents are not stepped) over the step launches' HIP-event time"}}
-    env.close()
+    # ---- C3 (Monza) and one island of C4 (Spa: BASELINE's 8 x (8192 x 32) is eight of these plus a 32 KB fitness all-gather per generation) ----
+    for key, track_name in (("c3", "Monza"), ("c4_island", "Spa")):
+        N, R = 8192, 32
+        track = ok.Track(track_name)
+        env = ok.BatchedEnvironment.from_track(track, N, R, device=local_rank)
+        ga = EvolutionaryRacer(env, track, hidden=30, seed=args.seed, agent_base=0, max_steps=4000, steps_per_launch=args.steps_per_launch,
+                               device=torch.device("cuda", local_rank))
+        ga.run_generation()
+        env.sync()
+        env.set_timing(True)
+        t0 = time.perf_counter()
+        recs = [ga.run_generation() for _ in range(2)]
+        env.sync()
+        dt = time.perf_counter() - t0
+        kernel_ms, launches = env.get_timing()
+        env.set_timing(False)
+        steps = sum(r["steps"] for r in recs)
+        live = sum(r["live_agent_steps"] for r in recs)
+        b_alg = C3_BYTES_STATE + 4.0 * R + 16.0 * track.S / N
+        b_w = 4.0 * ((R + 2) * 30 + 30 * 6)  # the agent's 1200 policy weights, read once per live agent-step when not cached
+        out[key] = {
+            "value": N * steps / dt, "live_value": live / dt, "unit": "agent-steps/s", "ms_per_step": dt / steps * 1e3,
+            "generation_ms": [1e3 * (r["rollout_s"] + r["select_mate_s"]) for r in recs], "steps": [r["steps"] for r in recs],
+            "live_fraction": live / float(N * steps), "kernel_ms_step_launches": kernel_ms, "launches": int(launches),
+            "workload": "%s: EvolutionaryRacer, %d agents x %d rays, %s.csv, fused 34-30-6 MLP policy + Environment::step, rollout until all "
+                        "crashed, score, select top-5, mate; 2 generations after 1 warm-up%s"
+                        % ("C3" if key == "c3" else "C4, ONE island on one GPU", N, R, track_name,
+                           "" if key == "c3" else " (the 8-GPU config adds the per-generation fitness all-gather: bench.py --config c4 --gpus 8)"),
+            "roofline": {"bound": "hbm", "algorithmic_bytes_per_agent_step": b_alg + b_w, "of_which_policy_weights": b_w,
+                         "achieved": (b_alg + b_w) * live / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (b_alg + b_w) * live / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else None,
+                         "note": "bytes of LIVE agent-steps (crashed agents are not stepped) over the step launches' HIP-event time"}}
+        env.close()
     # ---- C5 ----
     N, R = 16384, 16
     track = ok.Track("Silverstone")

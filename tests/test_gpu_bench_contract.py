@@ -33,7 +33,7 @@ def test_default_run_prints_the_contract_line(gpu):
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 100 and "sample" in cb
     bp = j["broad_phase"]
     assert 1.0 < bp["s_tested_per_ray"] < 20.0 and bp["segments"] == 4712 and 0 < bp["valu_fraction"] < 1
-    for name, n_agents in (("c3", 8192), ("c5", 16384)):
+    for name, n_agents in (("c3", 8192), ("c4_island", 8192), ("c5", 16384)):
         c = j["configs"][name]
         assert c["value"] > c["live_value"] > 1e7 and 0.02 < c["live_fraction"] < 0.6
         assert str(n_agents) in c["workload"] and c["roofline"]["frac"] < 1
