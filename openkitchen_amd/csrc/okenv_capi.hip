@@ -663,8 +663,10 @@ int launchStep(okenv *h, OkStepParams p) // (by value: the diagnostic build adds
     const bool q_launch = p.action_source == kActionsQLearning;
     if (p.active != nullptr && (policy == kPolicyMlp || q_launch) && p.n_active > 0)
     {
-        const unsigned lanes = static_cast<unsigned>(((h->R * kTailSplit + 63) / 64) * 64);
-        const size_t   lds   = h->image_bytes + 16U + sizeof(float) * kTailLdsFloats + (q_launch ? qLdsBytes(h) : 0U);
+        // (Q-learning: one more wave, without rays -- it looks up the nearest centre-line index while the others walk -- and the
+        // agent's table in LDS)
+        const unsigned lanes = static_cast<unsigned>(((h->R * kTailSplit + 63) / 64) * 64) + (q_launch ? 64U : 0U);
+        const size_t   lds   = h->image_bytes + 16U + sizeof(float) * kTailLdsFloats + (q_launch ? qLdsBytes(h) + sizeof(float) * kTailQFloats : 0U);
         if (p.n_active <= tailLimit(h, q_launch))
         {
             p.G = h->G; // (unused by the tail kernel; undo the widening above)
@@ -766,7 +768,7 @@ long tailLimit(const okenv *h, const bool q_launch)
     if (h->grid_mode != kGridLds || !h->coop || h->tail_max_agents == 0)
         return 0;
     const unsigned lanes = static_cast<unsigned>(((h->R * kTailSplit + 63) / 64) * 64);
-    const size_t   lds   = h->image_bytes + 16U + sizeof(float) * kTailLdsFloats + (q_launch ? qLdsBytes(h) : 0U);
+    const size_t   lds   = h->image_bytes + 16U + sizeof(float) * kTailLdsFloats + (q_launch ? qLdsBytes(h) + sizeof(float) * kTailQFloats : 0U);
     if (lanes > 512U || lds > kLdsBudget)
         return 0;
     const long fit = static_cast<long>(kLdsBudget / lds) * 256L;

@@ -953,19 +953,29 @@ __device__ __forceinline__ int okNearestBucketed(const OkStepParams &p, const fl
 // moved on.  `writer`: the one lane that stores the learned value.
 __device__ __forceinline__ void okQLearnStep(const OkStepParams &p, float *q_row0, const bool writer, const bool crashed, const int next_state,
                                              const int nearest, const float n0, const float n1, const float n2, OkQCarry &qs, float &c0, float &c1,
-                                             float &c2)
+                                             float &c2, float *mirror = nullptr) // mirror: the workgroup's copy of the agent's table (tail kernel)
 {
     int         prev   = qs.prev; // (a local: the address of a member would put the whole struct on the stack)
     const float reward = ok_q_reward(crashed ? 1 : 0, nearest, &prev, p.P);
     qs.prev            = prev;
-    float       mq     = n0;
-    mq                 = (n1 > mq) ? n1 : mq;
-    mq                 = (n2 > mq) ? n2 : mq;
+    // The next state's row as learn() sees it, i.e. BEFORE this step's update.  When the agent stays in its state that row is the
+    // carried one -- and must be taken from there: the value read from the table may already contain this step's update where
+    // several waves hold one agent (okStepTailKernel: each wave reads for itself, one lane of one wave writes).
+    const bool  same   = next_state == qs.state;
+    float       mq     = same ? c0 : n0;
+    const float m1     = same ? c1 : n1;
+    const float m2     = same ? c2 : n2;
+    mq                 = (m1 > mq) ? m1 : mq;
+    mq                 = (m2 > mq) ? m2 : mq;
     float      *cell   = q_row0 + qs.state * OK_Q_ACTIONS + qs.action;
     const float old_q  = (qs.action == 0) ? c0 : ((qs.action == 1) ? c1 : c2);
     const float new_q  = ok_q_learn(old_q, mq, reward);
     if (writer)
+    {
         __hip_atomic_store(cell, new_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mirror != nullptr)
+            mirror[qs.state * OK_Q_ACTIONS + qs.action] = new_q;
+    }
     // the row carried into the next step: the current one with the learned value, or the next state's
     c0 = (qs.action == 0) ? new_q : c0;
     c1 = (qs.action == 1) ? new_q : c1;
@@ -1730,17 +1740,24 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
 // LDS: [ image | 16 B unused | dist[2][64] | dist / 200 [2][64] (the MLP's inputs, divided once by the ray's lane) | min[2][8] |
 //        Q-learning: centre line + buckets ]
 constexpr int kTailSplit     = 8;
-constexpr int kTailLdsFloats = 4 * 64 + 2 * 8;
+constexpr int kTailLdsFloats = 4 * 64 + 2 * 16;
+// Q-learning: one more wave per workgroup (it has no rays: while the others walk theirs it finds the nearest centre-line index of
+// the new position, which depends on the move only), and the agent's whole table in LDS for the launch -- this workgroup is the
+// only one that touches it, learned values are written through to memory -- so that the next state's row costs an LDS round trip
+// instead of an L2 one: what is left of the step after its barrier is the table arithmetic.
+constexpr int kTailQFloats   = OK_Q_STATES * OK_Q_ACTIONS + 7; // the table, nearest index [2], padding
 
 template <int kPolicy, int kR>
-__global__ void __launch_bounds__(512) okStepTailKernel(const OkStepParams p, const uint32_t off_tail)
+__global__ void __launch_bounds__(kPolicy == kPolicyQ ? 576 : 512) okStepTailKernel(const OkStepParams p, const uint32_t off_tail)
 {
     static_assert(kPolicy != kPolicyNone, "policy kernels only");
     extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
     float    *s_dist     = reinterpret_cast<float *>(ok_lds + off_tail + 16);
     float    *s_xs       = s_dist + 2 * 64;
     float    *s_min      = s_xs + 2 * 64;
-    float    *lds_cx     = s_min + 2 * 8;
+    float    *s_qtab     = s_min + 2 * 16;                                        // (Q-learning only, as is everything behind it)
+    int      *s_near     = reinterpret_cast<int *>(s_qtab + OK_Q_STATES * OK_Q_ACTIONS);
+    float    *lds_cx     = s_qtab + kTailQFloats;
     float    *lds_cy     = lds_cx + p.P;
     uint16_t *lds_cstart = reinterpret_cast<uint16_t *>(lds_cy + p.P);
     uint16_t *lds_cidx   = lds_cstart + (p.geom.nx * p.geom.ny + 1);
@@ -1788,6 +1805,8 @@ __global__ void __launch_bounds__(512) okStepTailKernel(const OkStepParams p, co
         qs.action        = p.q_action[a];
         qs.prev          = p.q_prev_idx[a];
         q_row0           = p.q_table + static_cast<size_t>(a) * (OK_Q_STATES * OK_Q_ACTIONS);
+        for (int i = L; i < OK_Q_STATES * OK_Q_ACTIONS; i += static_cast<int>(blockDim.x)) // (first read after the first step's barrier)
+            s_qtab[i] = __hip_atomic_load(q_row0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float *row = q_row0 + qs.state * OK_Q_ACTIONS;
         qc0              = __hip_atomic_load(row + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         qc1              = __hip_atomic_load(row + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1839,7 +1858,7 @@ __global__ void __launch_bounds__(512) okStepTailKernel(const OkStepParams p, co
         const float *xs_in    = s_xs + (s & 1) * 64;         // written by the step before (or above)
         float       *dist_out = s_dist + ((s & 1) ^ 1) * 64;
         float       *xs_out   = s_xs + ((s & 1) ^ 1) * 64;
-        float       *min_out  = s_min + ((s & 1) ^ 1) * 8;
+        float       *min_out  = s_min + ((s & 1) ^ 1) * 16;
         const bool   was_crashed = ag.crashed;
         const bool   q_frozen    = kPolicy == kPolicyQ && episode && was_crashed;
         if (kPolicy == kPolicyMlp)
@@ -1897,6 +1916,12 @@ __global__ void __launch_bounds__(512) okStepTailKernel(const OkStepParams p, co
             found          = ok_cast_poly_interval<false>(view, ox, oy, rdx, rdy, ta, tb, nullptr, nullptr, nullptr, OK_TWALK, part > 0).min_t;
         }
         found = okGroupMin(found, kTailSplit);
+        if (kPolicy == kPolicyQ && wave == n_waves - 1)
+        { // the wave without rays: RaceTrack::findNearestTrackIndexBruteForce of the new position, while the others walk
+            const int nearest_here = okNearestBucketed(p, lds_cx, lds_cy, lds_cstart, lds_cidx, ag.pos_x, ag.pos_y, lane, 64);
+            if (lane == 0)
+                s_near[(s & 1) ^ 1] = nearest_here;
+        }
         OK_TSTAMP(3);
         float min_d2 = OK_SENSOR_RANGE * OK_SENSOR_RANGE;
         if (out_ok)
@@ -1945,18 +1970,14 @@ __global__ void __launch_bounds__(512) okStepTailKernel(const OkStepParams p, co
                 next_state += ok_q_bin(dist_out[p.q_ray[i]]) * mult;
                 mult *= 3;
             }
-            float n0 = 0.F, n1 = 0.F, n2 = 0.F;
+            // the next state's row from the workgroup's copy of the table (a row other than the current state's: nobody writes it in
+            // this step; the current state's own row is the carried one, okQLearnStep), the nearest index from the wave without rays
+            const float *nrow    = s_qtab + next_state * OK_Q_ACTIONS;
+            const float  n0      = nrow[0], n1 = nrow[1], n2 = nrow[2];
+            const int    nearest = s_near[(s & 1) ^ 1];
             if (!q_frozen)
             {
-                const float *nrow = q_row0 + next_state * OK_Q_ACTIONS;
-                n0                = __hip_atomic_load(nrow + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                n1                = __hip_atomic_load(nrow + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                n2                = __hip_atomic_load(nrow + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            const int nearest = okNearestBucketed(p, lds_cx, lds_cy, lds_cstart, lds_cidx, ag.pos_x, ag.pos_y, lane, 64);
-            if (!q_frozen)
-            {
-                okQLearnStep(p, q_row0, L == 0, ag.crashed, next_state, nearest, n0, n1, n2, qs, qc0, qc1, qc2);
+                okQLearnStep(p, q_row0, L == 0, ag.crashed, next_state, nearest, n0, n1, n2, qs, qc0, qc1, qc2, s_qtab);
                 if (ag.crashed && episode && L == 0)
                     p.q_next_state[okOpaque(a)] = next_state;
             }
