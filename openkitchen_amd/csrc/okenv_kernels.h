@@ -1883,13 +1883,14 @@ __global__ void __launch_bounds__(kPolicy == kPolicyQ ? 576 : 512) okStepTailKer
             }
             const float h = (acc > 0.F) ? acc : 0.F;
             float       z = 0.F;
+            // (the whole wave holds the one agent: lane i's value by v_readlane, no LDS round trip)
 #pragma unroll
             for (int i = 0; i < OK_MLP_HID_PAD; ++i)
-                z = z + __shfl(h, i, 64) * vcol[i];
+                z = z + okFromBits(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(okBits(h)), i))) * vcol[i];
             float zs[OK_MLP_OUT];
 #pragma unroll
             for (int q = 0; q < OK_MLP_OUT; ++q)
-                zs[q] = __shfl(z, q, 64);
+                zs[q] = okFromBits(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(okBits(z)), q)));
             ok_ga_decode_action(zs, &ag.thr, &ag.steer);
         }
         if (kPolicy == kPolicyQ && !q_frozen)
