@@ -1745,7 +1745,7 @@ constexpr int kTailLdsFloats = 4 * 64 + 2 * 16;
 // the new position, which depends on the move only), and the agent's whole table in LDS for the launch -- this workgroup is the
 // only one that touches it, learned values are written through to memory -- so that the next state's row costs an LDS round trip
 // instead of an L2 one: what is left of the step after its barrier is the table arithmetic.
-constexpr int kTailQFloats   = OK_Q_STATES * OK_Q_ACTIONS + 7; // the table, nearest index [2], padding
+constexpr int kTailQFloats   = OK_Q_STATES * OK_Q_ACTIONS + 7; // the table, nearest index [2], the next step's epsilon-greedy draw [2], padding
 
 template <int kPolicy, int kR>
 __global__ void __launch_bounds__(kPolicy == kPolicyQ ? 576 : 512) okStepTailKernel(const OkStepParams p, const uint32_t off_tail)
@@ -1894,9 +1894,10 @@ __global__ void __launch_bounds__(kPolicy == kPolicyQ ? 576 : 512) okStepTailKer
             ok_ga_decode_action(zs, &ag.thr, &ag.steer);
         }
         if (kPolicy == kPolicyQ && !q_frozen)
-        {
-            qs.action = ok_q_choose_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s), p.q_epsilon,
-                                           qc0, qc1, qc2);
+        { // the epsilon-greedy draw of this step was made by the wave without rays during the step before (it depends on the step's
+          // number only); the first step of a launch makes its own
+            const int drawn = (s == 0) ? ok_q_draw_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base, p.q_epsilon) : s_near[2 + (s & 1)];
+            qs.action       = drawn < 0 ? ok_q_argmax3(qc0, qc1, qc2) : drawn;
             ok_q_action_values(qs.action, &ag.thr, &ag.steer);
         }
         OK_TSTAMP(0);
@@ -1921,7 +1922,10 @@ __global__ void __launch_bounds__(kPolicy == kPolicyQ ? 576 : 512) okStepTailKer
         { // the wave without rays: RaceTrack::findNearestTrackIndexBruteForce of the new position, while the others walk
             const int nearest_here = okNearestBucketed(p, lds_cx, lds_cy, lds_cstart, lds_cidx, ag.pos_x, ag.pos_y, lane, 64);
             if (lane == 0)
-                s_near[(s & 1) ^ 1] = nearest_here;
+            {
+                s_near[(s & 1) ^ 1]     = nearest_here;
+                s_near[2 + ((s & 1) ^ 1)] = ok_q_draw_action(p.seed, p.agent_base + static_cast<uint32_t>(a), p.step_base + static_cast<uint32_t>(s) + 1U, p.q_epsilon);
+            }
         }
         OK_TSTAMP(3);
         float min_d2 = OK_SENSOR_RANGE * OK_SENSOR_RANGE;
