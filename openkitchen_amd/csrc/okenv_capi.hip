@@ -692,6 +692,8 @@ int launchStep(okenv *h, OkStepParams p) // (by value: the diagnostic build adds
                 hipLaunchKernelGGL((okStepTailKernel<kPolicyQ, 0>), tgrid, tblock, lds, h->stream, p, off);
             else if (h->R == 32)
                 hipLaunchKernelGGL((okStepTailKernel<kPolicyMlp, 32>), tgrid, tblock, lds, h->stream, p, off);
+            else if (h->R == 15) // the reference's own fan (Agent.cpp:13-17; EvolutionaryRacer's 17-30-6 network): weights in registers as well
+                hipLaunchKernelGGL((okStepTailKernel<kPolicyMlp, 15>), tgrid, tblock, lds, h->stream, p, off);
             else
                 hipLaunchKernelGGL((okStepTailKernel<kPolicyMlp, 0>), tgrid, tblock, lds, h->stream, p, off);
             OK_HIP(h, hipGetLastError());
@@ -921,6 +923,8 @@ extern "C"
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyMlp, false, false, false, 32>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepTailKernel<kPolicyMlp, 32>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
+            OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepTailKernel<kPolicyMlp, 15>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepTailKernel<kPolicyMlp, 0>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
