@@ -407,7 +407,7 @@ def bench_qlearning(args, ok, torch, dist, rank, world, local_rank, log):
 def launch_ranks(n, argv):
     """Starts `n` ranks of this script (one per GPU) through torch.distributed.run and returns their exit code.  Runs in a
     process that has not imported torch, let alone touched the GPU; the ranks are fresh children, nothing is exec'ed.  Rank 0's
-    stdout (the ONE JSON line) is relayed as it comes; stderr is shared."""
+    stdout (the ONE JSON line) is relayed as it comes, anything else found there goes to stderr; stderr is shared."""
     import socket
     import subprocess
 
@@ -424,8 +424,11 @@ def launch_ranks(n, argv):
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
     try:
         for line in child.stdout:
-            sys.stdout.write(line)
-            sys.stdout.flush()
+            # stdout carries the ONE JSON line; whatever else the ranks' libraries print there (gloo announces its connections
+            # on stdout) goes to stderr
+            out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+            out.write(line)
+            out.flush()
         return child.wait()
     except BaseException:
         child.terminate()  # the exact process we started; torchrun forwards the signal to its ranks

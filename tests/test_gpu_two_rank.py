@@ -43,6 +43,7 @@ def plain_bench(*args):
     assert "starting the ranks" in r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert [l for l in r.stdout.splitlines() if l.strip()] == lines, r.stdout[-2000:]  # nothing but the line (gloo's chatter went to stderr)
     return json.loads(lines[0])
 
 
