@@ -53,7 +53,7 @@ def device_ga_loop(dev, spl, cap):
 
 
 @pytest.mark.parametrize("track_name,N,R,spl", [("Monza", 96, 32, 50), ("Monza", 96, 32, 7), ("Austin", 40, 15, 1000), ("Silverstone", 24, 64, 33),
-                                                ("Spa", 300, 32, 20), ("Monza", 3, 8, 16)])
+                                                ("Spa", 200, 32, 20), ("Monza", 3, 8, 16)])
 def test_ga_episode_equals_reference_loop(gpu, oracle, track_name, N, R, spl):
     t, dev, orc, ga = make_ga(gpu, oracle, track_name, N, R)
     start = (float(t.x[3]), float(t.y[3]), float(t.heading[0]))

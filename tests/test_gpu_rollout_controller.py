@@ -52,12 +52,12 @@ def same_everything(gpu, oracle, dev, orc, where):
 
 
 @pytest.mark.parametrize("track,N,R,hidden,kind", [("Silverstone", 300, 5, 16, 1), ("Monza", 64, 15, 32, 1), ("Austin", 33, 9, 6, 0),
-                                                   ("Spa", 40, 64, 64, 1), ("Silverstone", 2100, 5, 16, 1)])
+                                                   ("Spa", 40, 64, 64, 1), ("Silverstone", 1100, 5, 16, 1)])
 def test_rollout_controller_equals_the_three_calls(gpu, oracle, track, N, R, hidden, kind):
     fan = RAYS if R == 5 else gpu.default_ray_fan(R)
     t, dev, orc, params, rng = make(gpu, oracle, track, N, fan, hidden, kind, seed=hidden + R)
     done = 0
-    for n in (1, 7, 30, 2, 110, 70, 45):  # crashes from the first dozens of steps on, standstill timeouts at step 201
+    for n in (1, 7, 30, 110, 70, 45):  # crashes from the first dozens of steps on, standstill timeouts at step 201
         dev.rollout_controller(n, 100.0, 5.0)
         for _ in range(n):
             oracle_iteration(oracle, orc, params, hidden)
