@@ -1429,7 +1429,9 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
             }
             float sr, cr;
             float rdx = 1.F, rdy = 0.F;
-            okAgentPreStep(p, ag, a, s, sr, cr, ray_deg, &rdy, &rdx, have_drawn, ra_now);
+            // (direct dealing with an even number of lanes per ray: lanes 2i and 2i + 1 hold the same ray and share the two fp64
+            // evaluations, as in the tail kernel)
+            okAgentPreStep(p, ag, a, s, sr, cr, ray_deg, &rdy, &rdx, have_drawn, ra_now, direct && (dm & 1) == 0);
             const float ox     = ag.pos_x + p.sensor_offset * cr;
             const float oy     = ag.pos_y + p.sensor_offset * sr;
             const bool  casts  = ray_ok && !ag.crashed;
