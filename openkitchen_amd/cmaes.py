@@ -29,8 +29,8 @@ except ImportError:  # pragma: no cover
     _threadpool_limits = None
 
 
-def _few_blas_threads():
-    return _threadpool_limits(limits=4) if _threadpool_limits is not None else contextlib.nullcontext()
+def _few_blas_threads(n=4):
+    return _threadpool_limits(limits=n) if _threadpool_limits is not None else contextlib.nullcontext()
 
 
 class CmaEsSolver:
@@ -63,7 +63,7 @@ class CmaEsSolver:
 
     def sample(self):
         """Candidates x_i = mean + sigma * B (D * z_i), z_i ~ N(0, I); returns float32 [population, num_params]."""
-        with _few_blas_threads():
+        with _few_blas_threads(1):  # (250 x 250: 2.8 ms on one thread, 3.6 ms on four or more -- measured on the GPU box's host)
             evals, self.B = np.linalg.eigh(self.C)
         self.D = np.sqrt(evals)
         if self.device is None:
