@@ -103,8 +103,9 @@ class CmaEsSolver:
         old_mean = self.mean
         self.mean = mean
         y_w = (self.mean - old_mean) / self.sigma
-        inv_sqrt_c = (self.B / self.D) @ self.B.T
-        self.p_sigma = (1.0 - self.c_sigma) * self.p_sigma + np.sqrt(self.c_sigma * (2.0 - self.c_sigma) * self.mu_eff) * (inv_sqrt_c @ y_w)
+        # C^(-1/2) y_w = B diag(1 / D) B^T y_w as three matrix-vector products (the n x n matrix itself is never needed)
+        inv_sqrt_c_y = self.B @ ((self.B.T @ y_w) / self.D)
+        self.p_sigma = (1.0 - self.c_sigma) * self.p_sigma + np.sqrt(self.c_sigma * (2.0 - self.c_sigma) * self.mu_eff) * inv_sqrt_c_y
         self.p_c = (1.0 - self.c_c) * self.p_c + np.sqrt(self.c_c * (2.0 - self.c_c) * self.mu_eff) * y_w
         self.C = (1.0 - self.c_1 - self.c_mu) * self.C + self.c_1 * np.outer(self.p_c, self.p_c) + self.c_mu * rank_mu
         self.sigma *= np.exp((self.c_sigma / self.d_sigma) * (np.linalg.norm(self.p_sigma) / self.chi_n - 1.0))
