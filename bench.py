@@ -330,7 +330,7 @@ def bench_evolution(args, ok, torch, dist, rank, world, local_rank, log):
     elapsed_max = sharding.max_over_ranks(elapsed, device=args.tensor_dev)
     steps = sum(r["steps"] for r in recs)
     steps_t = torch.tensor([float(steps), float(sum(r["live_agent_steps"] for r in recs))], dtype=torch.float64, device=args.tensor_dev)
-    if world > 1:
+    if args.dist_on:
         dist.all_reduce(steps_t)
     if rank == 0:
         total_agent_steps = N * float(steps_t[0].item())
@@ -343,16 +343,18 @@ def bench_evolution(args, ok, torch, dist, rank, world, local_rank, log):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: EvolutionaryRacer, %d agents x %d rays per GPU, %s.csv, fused 34-30-6 MLP policy + step, "
                                    "rollout until all crashed (<= 4000 steps), score, select top-5, mate%s"
-                                   % (args.config.upper(), N, R, track_name, ", RCCL fitness all-gather per generation" if world > 1 else ""),
+                                   % (args.config.upper(), N, R, track_name, ", %s fitness all-gather per generation" % ("RCCL" if args.dist_backend == "nccl" else "gloo") if args.dist_on else ""),
                        "generations": args.generations, "parallelism": "dp%d island populations" % world},
             "generation_wall_s": elapsed_max / args.generations,
+            "dist": dist_record(args, dist, world),
+            "all_gather_us": [1e6 * r["all_gather_s"] for r in recs],
             # (for profiles taken over the whole process: rank 0's live agent-steps including the warm-up generation)
             "rank0_live_agent_steps_with_warmup": int(warm["live_agent_steps"] + sum(r["live_agent_steps"] for r in recs)),
             "rank0_steps_with_warmup": int(warm["steps"] + steps),
-            "generations": [{k: r[k] for k in ("generation", "steps", "live_agent_steps", "rollout_s", "select_mate_s", "island_best", "island_mean", "colony_best", "colony_mean")} for r in recs],
+            "generations": [{k: r[k] for k in ("generation", "steps", "live_agent_steps", "rollout_s", "select_mate_s", "all_gather_s", "island_best", "island_mean", "colony_best", "colony_mean")} for r in recs],
         }), flush=True)
     env.close()
-    if world > 1:
+    if args.dist_on:
         sharding.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
@@ -382,7 +384,7 @@ def bench_qlearning(args, ok, torch, dist, rank, world, local_rank, log):
     sharding.barrier(device_ids=[local_rank])
     elapsed_max = sharding.max_over_ranks(elapsed, device=args.tensor_dev)
     steps_t = torch.tensor([float(steps), float(sum(r["live_agent_steps"] for r in recs))], dtype=torch.float64, device=args.tensor_dev)
-    if world > 1:
+    if args.dist_on:
         dist.all_reduce(steps_t)
     if rank == 0:
         table = env.q_table()
@@ -394,14 +396,24 @@ def bench_qlearning(args, ok, torch, dist, rank, world, local_rank, log):
             "config": {"workload": "C5: tabular Q-learning, %d agents x %d rays per GPU, %s.csv, epsilon-greedy + reward + Q update fused into "
                                    "the step kernel, 243x3 table per agent (%.1f MB)" % (N, R, args.track, N * 243 * 3 * 4 / 1e6),
                        "episodes": len(recs), "parallelism": "dp%d" % world},
+            "dist": dist_record(args, dist, world),
             "episodes": recs, "learned_entries_fraction": float((table > -1e30).mean()),
             "rank0_live_agent_steps_with_warmup": int(warm["live_agent_steps"] + sum(r["live_agent_steps"] for r in recs)),
             "rank0_steps_with_warmup": int(warm["steps"] + steps),
         }), flush=True)
     env.close()
-    if world > 1:
+    if args.dist_on:
         sharding.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
+
+
+def dist_record(args, dist, world):
+    """What the line says about the process group its collectives ran on (None: no group, every collective was skipped)."""
+    if not (args.dist_on and dist.is_initialized()):
+        return None
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "forced_at_world_1": bool(args.force_dist and world == 1),
+            "collectives": "barrier(device_ids), all_reduce(MAX) of the region times, all_reduce(SUM) of the step counts"
+                           + (", all_gather_into_tensor of the fitness vector per generation" if args.config == "c4" or args.config == "c3" else "")}
 
 
 def launch_ranks(n, argv):
@@ -458,6 +470,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, default).  gloo + --single-device rehearses the multi-process path on a one-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the process group at world size 1 too (RANK 0 of 1, 127.0.0.1): the barriers, the max-over-ranks "
+                         "all-reduce and C4's fitness all-gather then run on a real one-rank RCCL communicator instead of being skipped")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the secondary one-launch-per-step and host-boundary loops (used under rocprofv3 so that the "
                          "kernel trace holds only the timed region's launches)")
@@ -483,21 +498,32 @@ def main():
     import torch
     import torch.distributed as dist
 
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:  # --force-dist started plainly: this process is rank 0 of 1, no launcher, nothing re-exec'ed
+            import socket
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(s.getsockname()[1]))
+            s.close()
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("LOCAL_RANK", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the Environment step has no CPU fallback")
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     tensor_dev = "cuda" if args.dist_backend == "nccl" else "cpu"  # where the tiny timing tensors live
-    if world > 1:
+    if dist_on:  # the first thing that touches the GPU after set_device: the RCCL communicator
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="gloo")
     args.tensor_dev = tensor_dev
+    args.dist_on = dist_on
 
     def log(msg):
         if rank == 0:
@@ -673,6 +699,7 @@ def main():
             "value_one_launch_per_step": (N * one_steps / one_elapsed) if one_steps else None,
             "value_host_boundary_pcie_inclusive": (N * pcie_steps / pcie_elapsed) if pcie_steps else None,
             "crashed_fraction_at_end": crashed_frac,
+            "dist": dist_record(args, dist, world),
             "callers": callers,
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
@@ -694,7 +721,7 @@ def main():
                 log("cpu baseline failed: %s: %s" % (type(e).__name__, e))
         print(json.dumps(result), flush=True)
     env.close()
-    if world > 1:
+    if args.dist_on:
         sharding.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 

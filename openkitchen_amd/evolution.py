@@ -67,13 +67,17 @@ class EvolutionaryRacer:
             self.env.sync()  # the copy ran on the environment's stream; the collective runs on torch's
         else:
             local = torch.as_tensor(self.env.ga_scores(), dtype=torch.float32)
+        tg = time.perf_counter()
         colony = sharding.all_gather_fitness(local)  # [world, N]: global colony statistics (showColonyScore)
+        if on_gpu:
+            torch.cuda.current_stream(self.device).synchronize()
+        tg = time.perf_counter() - tg
         parents = self.env.ga_select_mate(self.seed, self.generation, self.agent_base)  # chooseAndMateAgents
         self.env.sync()
         t2 = time.perf_counter()
         stats = torch.stack([local.max(), local.mean(), colony.max(), colony.mean()]).tolist()  # four scalars leave the device
         rec = {"generation": self.generation, "steps": steps, "live_agent_steps": int(self.live_agent_steps), "rollout_s": t1 - t0,
-               "select_mate_s": t2 - t1,
+               "select_mate_s": t2 - t1, "all_gather_s": tg,
                "island_best": stats[0], "island_mean": stats[1], "colony_best": stats[2], "colony_mean": stats[3],
                "parents": [int(v) for v in parents]}
         self.history.append(rec)

@@ -12,6 +12,9 @@ import torch
 import torch.distributed as dist
 
 
+_PINNED = {}  # (numel, dtype) -> pinned staging buffer of the gloo rehearsal path
+
+
 def world():
     """(rank, world_size) of the default process group, (0, 1) when not initialised."""
     if dist.is_available() and dist.is_initialized():
@@ -34,8 +37,14 @@ def split_population(total_agents, world_size):
     return list(zip(starts, sizes))
 
 
+def group_active():
+    """True when a default process group exists -- at ANY world size: a one-rank RCCL communicator is a legal group and its
+    collectives run (bench.py --force-dist), so that world size 1 exercises the same lines as world size 8."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def barrier(device_ids=None):
-    if dist.is_available() and dist.is_initialized():
+    if group_active():
         if device_ids is not None and dist.get_backend() == "nccl":
             dist.barrier(device_ids=device_ids)
         else:
@@ -45,7 +54,7 @@ def barrier(device_ids=None):
 def max_over_ranks(value, device="cpu"):
     """MAX all-reduce of a python float (the benchmark's elapsed time)."""
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if group_active():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -53,24 +62,28 @@ def max_over_ranks(value, device="cpu"):
 def max_over_ranks_list(values, device="cpu"):
     """Element-wise MAX all-reduce of a list of python floats (the benchmark's per-repetition elapsed times)."""
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if group_active():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return [float(v) for v in t.tolist()]
 
 
 def all_gather_fitness(local_fitness):
     """All-gather of the per-rank fitness vector (1-D tensor, same length on every rank).  Returns [world, n]."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not group_active():
         return local_fitness.unsqueeze(0).clone()
     w, n = dist.get_world_size(), local_fitness.numel()
     if local_fitness.is_cuda and dist.get_backend() != "nccl":
         # gloo rehearsal of the GPU path (no RCCL between two ranks on one card): the device tensor is what the product hands
         # over, only the collective itself goes through a pinned host copy and the gathered matrix returns to the device
-        host = torch.empty(n, dtype=local_fitness.dtype, pin_memory=True)
-        host.copy_(local_fitness.view(-1))
+        key = (n, local_fitness.dtype)
+        host = _PINNED.get(key)
+        if host is None:
+            host = _PINNED[key] = torch.empty(n, dtype=local_fitness.dtype, pin_memory=True)
+        host.copy_(local_fitness.contiguous().view(-1))
         flat = torch.empty(w * n, dtype=local_fitness.dtype)
         dist.all_gather_into_tensor(flat, host)
         return flat.to(local_fitness.device).view(w, n)
+    # RCCL (any world size, 1 included) reads the device tensor; gloo gathers host tensors
     flat = torch.empty(w * n, dtype=local_fitness.dtype, device=local_fitness.device)
     dist.all_gather_into_tensor(flat, local_fitness.contiguous().view(-1))
     return flat.view(w, n)
@@ -124,7 +137,7 @@ def share_q_knowledge(env):
     """shareCumulativeKnowledge (reference RLRacers/Q_Learning/q_racer_sim.cpp:24-75) across every rank's population: the
     per-entry sums and counts of the valid Q values are all-reduced (2 x 729 floats = 5.8 KB) and every agent on every
     rank receives the mean.  With one process this is okenv_q_share_knowledge."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not group_active():
         env.q_share_knowledge()
         return
     import numpy as np
