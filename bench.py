@@ -88,9 +88,26 @@ def bench_secondary_configs(args, ok, torch, local_rank, log):
     from openkitchen_amd.qlearning import QLearningRacers
     out = {}
     # ---- C3 (Monza) and one island of C4 (Spa: BASELINE's 8 x (8192 x 32) is eight of these plus a 32 KB fitness all-gather per generation) ----
+    import torch.distributed as dist
     for key, track_name in (("c3", "Monza"), ("c4_island", "Spa")):
         N, R = 8192, 32
         track = ok.Track(track_name)
+        # the C4 island gathers its fitness vector over a ONE-rank RCCL communicator (a legal group; the 8-GPU config has eight
+        # ranks in it): the collective's lines run in the driver's default run too.  A failure to set it up must never cost the line.
+        own_group, dist_note = False, None
+        if key == "c4_island" and not dist.is_initialized():
+            try:
+                import socket
+                s = socket.socket()
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+                s.close()
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                        device_id=torch.device("cuda", local_rank))
+                own_group = True
+            except Exception as e:  # noqa: BLE001
+                dist_note = "no one-rank RCCL group (%s: %s): the fitness all-gather was skipped" % (type(e).__name__, e)
         env = ok.BatchedEnvironment.from_track(track, N, R, device=local_rank)
         ga = EvolutionaryRacer(env, track, hidden=30, seed=args.seed, agent_base=0, max_steps=4000, steps_per_launch=args.steps_per_launch,
                                device=torch.device("cuda", local_rank))
@@ -107,7 +124,14 @@ def bench_secondary_configs(args, ok, torch, local_rank, log):
         live = sum(r["live_agent_steps"] for r in recs)
         b_alg = C3_BYTES_STATE + 4.0 * R + 16.0 * track.S / N
         b_w = 4.0 * ((R + 2) * 30 + 30 * 6)  # the agent's 1200 policy weights, read once per live agent-step when not cached
+        dist_rec = None
+        if key == "c4_island":
+            dist_rec = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                        "all_gather_us": [1e6 * r["all_gather_s"] for r in recs]} if dist.is_initialized() else {"note": dist_note}
+        if own_group:
+            dist.destroy_process_group()
         out[key] = {
+            "dist": dist_rec,
             "value": N * steps / dt, "live_value": live / dt, "unit": "agent-steps/s", "ms_per_step": dt / steps * 1e3,
             "generation_ms": [1e3 * (r["rollout_s"] + r["select_mate_s"]) for r in recs], "steps": [r["steps"] for r in recs],
             "live_fraction": live / float(N * steps), "kernel_ms_step_launches": kernel_ms, "launches": int(launches),
@@ -334,7 +358,7 @@ def bench_evolution(args, ok, torch, dist, rank, world, local_rank, log):
         dist.all_reduce(steps_t)
     if rank == 0:
         total_agent_steps = N * float(steps_t[0].item())
-        print(json.dumps({
+        emit(args, {
             "metric": "agent-steps/sec", "value": total_agent_steps / elapsed_max, "unit": "agent-steps/s", "n_gpus": world,
             # agents x steps of the reference's loop (everybody is in it until the last agent has crashed); live_value counts the
             # agent-steps of agents that entered the step alive -- what is actually stepped
@@ -352,7 +376,7 @@ def bench_evolution(args, ok, torch, dist, rank, world, local_rank, log):
             "rank0_live_agent_steps_with_warmup": int(warm["live_agent_steps"] + sum(r["live_agent_steps"] for r in recs)),
             "rank0_steps_with_warmup": int(warm["steps"] + steps),
             "generations": [{k: r[k] for k in ("generation", "steps", "live_agent_steps", "rollout_s", "select_mate_s", "all_gather_s", "island_best", "island_mean", "colony_best", "colony_mean")} for r in recs],
-        }), flush=True)
+        })
     env.close()
     if args.dist_on:
         sharding.barrier(device_ids=[local_rank])
@@ -388,7 +412,7 @@ def bench_qlearning(args, ok, torch, dist, rank, world, local_rank, log):
         dist.all_reduce(steps_t)
     if rank == 0:
         table = env.q_table()
-        print(json.dumps({
+        emit(args, {
             "metric": "agent-steps/sec", "value": N * float(steps_t[0].item()) / elapsed_max, "unit": "agent-steps/s", "n_gpus": world,
             "live_value": float(steps_t[1].item()) / elapsed_max, "live_fraction": float(steps_t[1].item()) / (N * float(steps_t[0].item())),
             "steps": steps, "warmup": 0, "ms_per_step": elapsed_max / max(steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -400,11 +424,16 @@ def bench_qlearning(args, ok, torch, dist, rank, world, local_rank, log):
             "episodes": recs, "learned_entries_fraction": float((table > -1e30).mean()),
             "rank0_live_agent_steps_with_warmup": int(warm["live_agent_steps"] + sum(r["live_agent_steps"] for r in recs)),
             "rank0_steps_with_warmup": int(warm["steps"] + steps),
-        }), flush=True)
+        })
     env.close()
     if args.dist_on:
         sharding.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
+
+
+def emit(args, result):
+    """The run's one line, on the descriptor that was stdout when the script started."""
+    os.write(args.json_fd, (json.dumps(result) + "\n").encode())
 
 
 def dist_record(args, dist, world):
@@ -494,6 +523,14 @@ def main():
               "`python bench.py --gpus %d ...` or under torchrun with --nproc-per-node %d"
               % (rank, args.gpus, world, args.gpus, args.gpus), file=sys.stderr, flush=True)
         raise SystemExit(2)
+
+    # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner on stdout when a communicator is created,
+    # gloo announces its connections there.  The descriptor is put aside for the line and everything else that writes to fd 1
+    # from here on (Python or native) lands on stderr.
+    sys.stdout.flush()
+    args.json_fd = os.dup(1)
+    os.dup2(2, 1)
+    os.environ.setdefault("RCCL_LOG_LEVEL", "0")
 
     import torch
     import torch.distributed as dist
@@ -719,7 +756,7 @@ def main():
                 result.update(cpu_baseline(args.track, R, args.seed, log))
             except Exception as e:  # noqa: BLE001  (e.g. no C compiler for the oracle on this host)
                 log("cpu baseline failed: %s: %s" % (type(e).__name__, e))
-        print(json.dumps(result), flush=True)
+        emit(args, result)
     env.close()
     if args.dist_on:
         sharding.barrier(device_ids=[local_rank])

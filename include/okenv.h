@@ -333,6 +333,13 @@ OKENV_API int okenv_reset_all(okenv_t h, float x, float y, float rot_deg);
 /* assignScores (EvolutionaryRacer/MiscUtils.hpp:64-71): score = nearest centre-line index as float, kept on the
  * device for okenv_ga_select_mate; `out` (N floats, host or device) may be NULL. */
 OKENV_API int okenv_ga_scores(okenv_t h, float *out);
+/* Where that score vector lives: the device address of the N floats okenv_ga_scores fills (library-owned, valid for the
+ * handle's lifetime), and the hipStream_t the handle enqueues its work on.  With the two a multi-GPU caller runs its one
+ * collective -- the per-generation all-gather of this vector, SURVEY.md section 8e -- straight from device memory and in
+ * stream order behind the kernel that wrote it:  okenv_ga_scores(h, NULL); ncclAllGather(scores, colony, N, ncclFloat, comm,
+ * stream);  (openkitchen_amd/csrc/apps/genetic_learner_sim.cpp --gpus N). */
+OKENV_API int okenv_ga_scores_device(okenv_t h, const float **ptr);
+OKENV_API int okenv_get_stream(okenv_t h, void **hip_stream);
 /* chooseAndMateAgents (EvolutionaryRacer/Mating.hpp:108-166) with mate2AgentsSelective (:52-99): the 5 best agents
  * (ties to the lower index) become parents; offspring 0 clones the best, offspring 1 is the best mated with itself,
  * every other offspring draws two different parents proportionally to score; per weight 10 % mutation to U[-1,1),

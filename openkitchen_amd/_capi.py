@@ -47,6 +47,7 @@ SYMBOLS = [
     "okenv_tracker_update", "okenv_step_packed",
     "okenv_controller_create", "okenv_controller_num_params", "okenv_controller_set_params", "okenv_controller_act", "okenv_rollout_controller",
     "okenv_episode_begin", "okenv_episode_compact", "okenv_episode_end", "okenv_episode_tail_limit", "okenv_work_stats",
+    "okenv_ga_scores_device", "okenv_get_stream",
 ]
 
 
@@ -164,6 +165,8 @@ def load(build_if_missing=True):
     L.okenv_episode_compact.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.okenv_episode_end.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_uint64)]
     L.okenv_episode_tail_limit.argtypes = [vp, C.POINTER(i32)]
+    L.okenv_ga_scores_device.argtypes = [vp, C.POINTER(vp)]
+    L.okenv_get_stream.argtypes = [vp, C.POINTER(vp)]
     _lib = L
     return L
 

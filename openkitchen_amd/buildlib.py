@@ -80,6 +80,10 @@ def build(force=False, verbose=False):
 APPS_DIR = os.path.join(CSRC, "apps")
 BIN_DIR = os.path.join(PKG_DIR, "bin")
 APPS = ["genetic_learner_sim", "q_racer_sim"]
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+# genetic_learner_sim runs its islands' per-generation fitness all-gather over RCCL itself (ncclAllGather on the handles' streams)
+APP_EXTRA = {"genetic_learner_sim": ["-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROCM, "include"), "-pthread", "-L", os.path.join(ROCM, "lib"),
+                                     "-lrccl", "-lamdhip64", "-Wl,-rpath," + os.path.join(ROCM, "lib")]}
 
 
 def build_apps(verbose=False):
@@ -91,9 +95,10 @@ def build_apps(verbose=False):
     out = []
     for app in APPS:
         src, exe = os.path.join(APPS_DIR, app + ".cpp"), os.path.join(BIN_DIR, app)
-        if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(LIB_PATH)):
+        deps = [src, LIB_PATH] + [os.path.join(APPS_DIR, f) for f in os.listdir(APPS_DIR) if f.endswith(".h")]
+        if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
             cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", exe, src, "-L", PKG_DIR, "-lokenv",
-                   "-Wl,-rpath,$ORIGIN/.."]  # finds libokenv.so next to bin/, wherever the tree is
+                   "-Wl,-rpath,$ORIGIN/.."] + APP_EXTRA.get(app, [])  # finds libokenv.so next to bin/, wherever the tree is
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True, cwd=ROOT)

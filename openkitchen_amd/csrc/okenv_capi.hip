@@ -2076,6 +2076,26 @@ extern "C"
         return OKENV_OK;
     }
 
+    int okenv_ga_scores_device(okenv_t h, const float **ptr)
+    {
+        OK_QUIESCE(h);
+        if (!h || !ptr)
+            return OKENV_ERR_INVALID;
+        if (!h->d_score)
+            return fail(h, OKENV_ERR_STATE, "okenv_ga_scores_device: call okenv_policy_mlp_create first");
+        *ptr = h->d_score;
+        return OKENV_OK;
+    }
+
+    int okenv_get_stream(okenv_t h, void **hip_stream)
+    {
+        OK_QUIESCE(h);
+        if (!h || !hip_stream)
+            return OKENV_ERR_INVALID;
+        *hip_stream = static_cast<void *>(h->stream);
+        return OKENV_OK;
+    }
+
     int okenv_ga_select_mate(okenv_t h, uint32_t seed, uint32_t generation, uint32_t agent_base, int32_t *parents_out)
     {
         OK_QUIESCE(h);

@@ -33,7 +33,7 @@ def test_genetic_learner_sim_matches_oracle_replay(gpu, oracle, apps, tmp_path):
     assert out.count("EPISODE") == G
     raw = np.fromfile(dump, dtype=np.uint8)
     per = (R + 2) * 32 + 32 * 8
-    rec = 4 + 4 * N + 20
+    rec = 4 + 4 * N + 20 + 8
     assert raw.size == G * rec + 4 * per
     # replay on the oracle: genetic_learner_sim.cpp:47-96
     fan = gpu.default_ray_fan(R)
@@ -46,7 +46,9 @@ def test_genetic_learner_sim_matches_oracle_replay(gpu, oracle, apps, tmp_path):
         blob = raw[g * rec:(g + 1) * rec]
         steps = int(blob[:4].view(np.int32)[0])
         scores = blob[4:4 + 4 * N].view(np.float32)
-        parents = blob[4 + 4 * N:].view(np.int32)
+        parents = blob[4 + 4 * N:4 + 4 * N + 20].view(np.int32)
+        colony_best, colony_mean = blob[4 + 4 * N + 20:].view(np.float32)  # one island: the colony is the island
+        assert colony_best == scores.max() and colony_mean == np.float32(scores.astype(np.float64).sum() / N)
         ga.reset_all(*start)
         orc.step(1)
         it = 1

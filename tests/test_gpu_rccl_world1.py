@@ -22,6 +22,9 @@ def bench(*args):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    # stdout is the line and nothing else: RCCL's version banner (it prints one on stdout when a communicator is created) and
+    # every other library's chatter went to stderr
+    assert [l for l in r.stdout.splitlines() if l.strip()] == lines, r.stdout[-2000:]
     return json.loads(lines[0])
 
 
