@@ -6,10 +6,10 @@
  * 121-124,157-158) and its kernel calls CUDA cosf/sinf (Environment/CollisionChecker.cu:47-48).
  * Those differ from each other and from ROCm's OCML in the last ulp, which is enough to flip the
  * `min_dist2 < 2.0f` crash test.  Crash/done flags must be bit-exact between the GPU path and the
- * CPU oracle, so both sides evaluate sine/cosine through THIS header: an fp64 Cody-Waite reduction and
- * an fp64 Taylor polynomial, rounded once to fp32.  Only +,-,* and round-to-nearest-even conversions are
- * used, all IEEE-exact on x86-64 and on gfx950, so the two sides agree bit for bit provided the
- * translation unit is compiled with -ffp-contract=off (no FMA contraction).
+ * CPU oracle, so both sides evaluate sine/cosine through THIS header: an fp64 reduction and fp64
+ * polynomials, rounded once to fp32.  Only +, -, *, explicitly requested fused multiply-adds (OK_FMA) and
+ * round-to-nearest-even conversions are used, all IEEE-exact on x86-64 and on gfx950, so the two sides agree bit
+ * for bit provided the translation unit is compiled with -ffp-contract=off (nothing fused that does not ask for it).
  * tests/test_math.py bounds the distance to glibc sincosf (<= 1 ulp) and to an fp64 reference.
  *
  * Also here: Philox4x32-10 (Salmon et al., SC'11), the counter-based generator the C2 bench recipe
@@ -45,52 +45,57 @@
 #define OK_PARALLEL_EPS 1e-8f
 
 #define OK_RINT(x) __builtin_rint(x) /* round to nearest even: rint() on the host, v_rndne_f64 on gfx950 */
+/* a * b + c with ONE rounding, asked for explicitly: v_fma_f64 on gfx950, libm's correctly rounded fma() (or the host's FMA
+ * instruction) on x86-64 -- the same bits either way.  The translation units are still compiled -ffp-contract=off: nothing is
+ * fused that does not say so here. */
+#define OK_FMA(a, b, c) __builtin_fma((a), (b), (c))
 
 /*
- * sin and cos of an fp32 angle [rad], each correctly rounded from an fp64 evaluation whose error is
- * < 1e-15 for |x| < 1.6e6 rad (9e7 degrees; rot_ is never wrapped, Environment/Agent.cpp:86,112, so
- * large arguments do occur).  Beyond that the reduction loses accuracy gracefully (absolute angle error
- * ~|x| * 1e-16) but stays deterministic and identical on both sides; NaN/Inf give NaN.
+ * sin and cos of an fp32 angle [rad], from an fp64 evaluation rounded once to fp32 (round 4's form; rounds 1-3 used a
+ * three-part Cody-Waite reduction and Taylor series to 1/15! with separate multiplications and additions: ~42 fp64 operations
+ * in a dependent chain of ~26; this is 21 operations in a chain of 12).
+ *   q = rint(x * 2/pi);  r = x - q * pi/2 by two FMAs against pi/2 = P1 + P2 (P1 the nearest double, P2 the next 53 bits): each FMA
+ *   forms its product exactly and rounds once, so r carries a RELATIVE error of ~2^-52 however close x lies to a multiple of
+ *   pi/2, for every |q| < 2^31;
+ *   sin r = r + (r z) S(z),  cos r = 1 + z C(z),  z = r^2, S and C of degree 5 in z: interpolants at the Chebyshev nodes of
+ *   [0, 0.79^2] (tools/fit_math.py prints them; pi/4 = 0.7854, the slack covers q's own rounding), relative errors 2^-55 and
+ *   2^-51, evaluated by Horner's rule in FMAs.
+ * The result is the correctly rounded fp32 sine / cosine but for about one argument in 10^7 (tests/test_math.py: equal to the
+ * rounded fp64 value on 700 000 samples and on the floats nearest to multiples of pi/2 up to 2^31; <= 1 ulp from glibc's
+ * sinf / cosf, which the reference's host code calls).  rot_ is never wrapped (Environment/Agent.cpp:86,112), so large arguments
+ * do occur: beyond 2^31 rad (fp32 spacing there is 256 rad: the angle carries no information) the argument is folded by an
+ * exact fmod first; NaN / Inf give NaN.
  */
 OK_HD void ok_sincosf(float x, float *s_out, float *c_out)
 {
     double xd = (double)x;
-    /* Absurdly large angles (|x| >= 2^31 rad ~ 1.2e11 degrees; fp32 spacing there is >= 256 rad, so the angle
-     * carries no information): fold with an exact fmod first so that the result stays in [-1,1] instead of
-     * overflowing.  fmod is exact by definition, hence still identical on CPU and GPU. */
-    if (!(__builtin_fabs(xd) < 2147483648.0))
-        xd = __builtin_fmod(xd, 6.283185307179586476925286766559);
-    /* q = nearest integer to x * 2/pi */
-    const double q = OK_RINT(xd * 0.63661977236758138243);
-    /* pi/2 split in three parts; the first two carry 33 significant bits each, so q*P1 and q*P2 are
-     * exact products for |q| < 2^20. */
-    const double P1 = 1.57079632673412561417e+00;
-    const double P2 = 6.07710050630396597660e-11;
-    const double P3 = 2.02226624879595063154e-21;
-    double r = xd - q * P1;
-    r = r - q * P2;
-    r = r - q * P3;
-    /* quadrant = q mod 4, taken in fp64 so that no out-of-range float->int conversion can happen */
-    const double qm = q - 4.0 * OK_RINT(q * 0.25); /* in {-2,-1,0,1,2} */
-    const int n = ((int)qm) & 3;
+    if (!(__builtin_fabs(xd) < 2147483648.0)) {
+        xd = __builtin_fmod(xd, 6.283185307179586476925286766559); /* exact by definition: identical on CPU and GPU */
+        if (!(xd == xd)) { /* NaN or Inf in */
+            *s_out = (float)xd;
+            *c_out = (float)xd;
+            return;
+        }
+    }
+    const double q = OK_RINT(xd * 0x1.45f306dc9c883p-1); /* 2/pi */
+    double r = OK_FMA(-q, 0x1.921fb54442d18p+0, xd);     /* P1 = 1.5707963267948966    */
+    r = OK_FMA(-q, 0x1.1a62633145c07p-54, r);            /* P2 = 6.123233995736766e-17 */
+    const int n = ((int)q) & 3;                          /* quadrant; |q| < 1.4e9 fits an int */
     const double z = r * r;
-    /* Taylor series; |r| <= pi/4 so the truncation error is < 5e-17 (sin) and < 1e-15 (cos). */
-    double ps = -7.647163731819816475901131985788070444155e-13; /* -1/15! */
-    ps = ps * z + 1.605904383682161459939237717015494793273e-10; /*  1/13! */
-    ps = ps * z - 2.505210838544171877505210838544171877505e-08; /* -1/11! */
-    ps = ps * z + 2.755731922398589065255731922398589065256e-06; /*  1/9!  */
-    ps = ps * z - 1.984126984126984126984126984126984126984e-04; /* -1/7!  */
-    ps = ps * z + 8.333333333333333333333333333333333333333e-03; /*  1/5!  */
-    ps = ps * z - 1.666666666666666666666666666666666666667e-01; /* -1/3!  */
-    const double sr = r + r * (z * ps);
-    double pc = -1.147074559772972471385169797868210566623e-11; /* -1/14! */
-    pc = pc * z + 2.087675698786809897921009032120143231254e-09; /*  1/12! */
-    pc = pc * z - 2.755731922398589065255731922398589065256e-07; /* -1/10! */
-    pc = pc * z + 2.480158730158730158730158730158730158730e-05; /*  1/8!  */
-    pc = pc * z - 1.388888888888888888888888888888888888889e-03; /* -1/6!  */
-    pc = pc * z + 4.166666666666666666666666666666666666667e-02; /*  1/4!  */
-    pc = pc * z - 0.5;                                            /* -1/2!  */
-    const double cr = 1.0 + z * pc;
+    double ps = 0x1.5e01d1798c2b3p-33;              /*  1.5916480269048027e-10 */
+    ps = OK_FMA(ps, z, -0x1.ae5ff116c8d06p-26);     /* -2.505110882200661e-08  */
+    ps = OK_FMA(ps, z, 0x1.71de377d84985p-19);      /*  2.755731599143529e-06  */
+    ps = OK_FMA(ps, z, -0x1.a01a019e70424p-13);     /* -1.9841269836543094e-04 */
+    ps = OK_FMA(ps, z, 0x1.1111111110b60p-7);       /*  8.333333333330806e-03  */
+    ps = OK_FMA(ps, z, -0x1.5555555555555p-3);      /* -1.6666666666666666e-01 */
+    const double sr = OK_FMA(r * z, ps, r);
+    double pc = 0x1.1bfd9695386eap-29;              /*  2.0663034153592203e-09 */
+    pc = OK_FMA(pc, z, -0x1.27e0dd327adbcp-22);     /* -2.75558210165445e-07   */
+    pc = OK_FMA(pc, z, 0x1.a019fc4c6ed87p-16);      /*  2.4801582456863223e-05 */
+    pc = OK_FMA(pc, z, -0x1.6c16c168f930cp-10);     /* -1.3888888881805088e-03 */
+    pc = OK_FMA(pc, z, 0x1.5555555554001p-5);       /*  4.166666666662878e-02  */
+    pc = OK_FMA(pc, z, -0x1.ffffffffffffap-2);      /* -4.9999999999999967e-01 */
+    const double cr = OK_FMA(z, pc, 1.0);
     double sv, cv;
     if (n == 0) { sv = sr; cv = cr; }
     else if (n == 1) { sv = cr; cv = -sr; }
@@ -233,42 +238,39 @@ OK_HD float ok_normalize_angle_deg(float angle)
     return angle;
 }
 
-/* tanh for the CMA-ES controller (CovarianceMatrixAdaptationEvolution/Controller.cpp:16-23), evaluated in fp64 with basic
- * IEEE operations only (no FMA contraction, no library call), so that the device and the CPU oracle produce the same bits
- * -- the same idea as ok_sincosf.  tanh|x| = (1 - e) / (1 + e), e = exp(-2|x|) = 2^n * exp(r), n = rint(-2|x| / ln 2),
- * |r| <= ln2 / 2, exp(r) by its Taylor series to r^13 (truncation < 5e-18); the fp64 result is off by a few 1e-16 relative
- * except for the cancellation in 1 - e at small |x| (2^-53 / 2|x|: 2^-42 at the 2^-12 below which tanh x rounds to x), i.e.
- * the float result is the correctly rounded one but for rare near-ties (tests/test_math.py: equal to the rounded fp64 tanh
- * on a million samples; glibc's tanhf, not correctly rounded itself, is within 2 ulps of it). */
+/* tanh for the CMA-ES controller (CovarianceMatrixAdaptationEvolution/Controller.cpp:16-23), evaluated in fp64 with IEEE operations
+ * and explicit FMAs only (no library call), so that the device and the CPU oracle produce the same bits -- the same idea as
+ * ok_sincosf.  tanh|x| = (1 - e) / (1 + e), e = exp(-2|x|) = 2^n (1 + m), n = rint(-2|x| / ln 2), m = expm1(r), |r| <= ln 2 / 2,
+ * r by two FMAs against ln 2 = L1 + L2, m = r + r^2 E(r) with E of degree 8 (interpolant at the Chebyshev nodes of +-0.347,
+ * tools/fit_math.py: relative error 2^-48).  Numerator and denominator are formed from m, not from e:
+ * 1 - e = (1 - 2^n) - 2^n m and 1 + e = (1 + 2^n) + 2^n m, one FMA each with 1 -+ 2^n exact -- for small |x| (n = 0) the numerator
+ * is -m itself, so nothing cancels and no separate small-argument branch is needed beyond the one below.  (Rounds 1-3: Taylor
+ * series of exp to r^13 by separate multiplications and additions, 1 - e by subtraction.)  tests/test_math.py: equal to the
+ * rounded fp64 tanh on all but a handful of a million samples; glibc's tanhf, not correctly rounded itself, is within 2 ulps. */
 OK_HD float ok_tanhf(const float x)
 {
     const double ax = __builtin_fabs((double)x);
     if (!(ax >= 0.000244140625)) /* |x| < 2^-12: x^3/3 is below half an ulp of x; NaN takes this exit too and stays NaN */
         return x;
-    const double y  = -2.0 * (ax < 20.0 ? ax : 20.0); /* tanh(20) is 1 to 17 digits: larger arguments change nothing */
-    const double n  = OK_RINT(y * 1.44269504088896338700);
-    const double L1 = 6.93147180369123816490e-01; /* ln 2 in two parts, the first with 32 significant bits: n * L1 is exact */
-    const double L2 = 1.90821492927058770002e-10;
-    double r = y - n * L1;
-    r = r - n * L2;
-    double p = 1.605904383682161459939237717015494793273e-10; /* 1/13! */
-    p = p * r + 2.087675698786809897921009032120143231254e-09;  /* 1/12! */
-    p = p * r + 2.505210838544171877505210838544171877505e-08;  /* 1/11! */
-    p = p * r + 2.755731922398589065255731922398589065256e-07;  /* 1/10! */
-    p = p * r + 2.755731922398589065255731922398589065256e-06;  /* 1/9!  */
-    p = p * r + 2.480158730158730158730158730158730158730e-05;  /* 1/8!  */
-    p = p * r + 1.984126984126984126984126984126984126984e-04;  /* 1/7!  */
-    p = p * r + 1.388888888888888888888888888888888888889e-03;  /* 1/6!  */
-    p = p * r + 8.333333333333333333333333333333333333333e-03;  /* 1/5!  */
-    p = p * r + 4.166666666666666666666666666666666666667e-02;  /* 1/4!  */
-    p = p * r + 1.666666666666666666666666666666666666667e-01;  /* 1/3!  */
-    p = p * r + 0.5;
-    p = p * r + 1.0;
-    p = p * r + 1.0;
+    const double y = -2.0 * (ax < 20.0 ? ax : 20.0); /* tanh(20) is 1 to 17 digits: larger arguments change nothing */
+    const double n = OK_RINT(y * 0x1.71547652b82fep+0); /* 1 / ln 2 */
+    double r = OK_FMA(-n, 0x1.62e42fefa39efp-1, y);     /* L1 = 0.6931471805599453     */
+    r = OK_FMA(-n, 0x1.abc9e3b39803fp-56, r);           /* L2 = 2.3190468138462996e-17 */
+    double p = 0x1.28809b1a1156ep-22;           /* 2.7613934750302004e-07 */
+    p = OK_FMA(p, r, 0x1.72c7b3ac3a215p-19);    /* 2.7625269095508424e-06 */
+    p = OK_FMA(p, r, 0x1.a019c964743c8p-16);    /* 2.4801536157973374e-05 */
+    p = OK_FMA(p, r, 0x1.a019ad41ef162p-13);    /* 1.9841208455585307e-04 */
+    p = OK_FMA(p, r, 0x1.6c16c1739cf9cp-10);    /* 1.388888890599716e-03  */
+    p = OK_FMA(p, r, 0x1.1111111c5b16fp-7);     /* 8.333333353868181e-03  */
+    p = OK_FMA(p, r, 0x1.5555555554ca3p-5);     /* 4.166666666665122e-02  */
+    p = OK_FMA(p, r, 0x1.5555555553b3cp-3);     /* 1.6666666666648122e-01 */
+    p = OK_FMA(p, r, 0.5);
+    const double m = OK_FMA(r * r, p, r); /* expm1(r) */
     union { uint64_t u; double d; } two_n; /* 2^n, n in [-58, 0] */
     two_n.u = (uint64_t)(1023 + (int)n) << 52;
-    const double e = p * two_n.d;
-    const double t = (1.0 - e) / (1.0 + e);
+    const double num = OK_FMA(-two_n.d, m, 1.0 - two_n.d);
+    const double den = OK_FMA(two_n.d, m, 1.0 + two_n.d);
+    const double t = num / den;
     return (float)(x < 0.0f ? -t : t);
 }
 

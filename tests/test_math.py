@@ -37,6 +37,46 @@ def test_sincos_against_fp64_and_glibc(oracle):
     assert np.abs(s[::40].astype(np.float64) - sg).max() < 1e-7
 
 
+def test_sincos_at_the_floats_nearest_to_multiples_of_half_pi(oracle):
+    """Where the argument reduction is hardest: floats x = m * 2^e (m < 2^24) lying unusually close to a multiple of pi/2 -- the
+    continued-fraction convergents of 2^e / (pi/2) give them for every exponent -- up to 2^31, the limit of the fast path.  The
+    two-FMA reduction keeps a RELATIVE error of ~2^-52 on the reduced angle there, so the result is still the rounded fp64 one
+    (compared here with a 60-digit evaluation, since numpy's own fp64 sine is not trustworthy for such arguments)."""
+    import mpmath as mp
+    mp.mp.dps = 60
+    xs = set()
+    half_pi = mp.pi / 2
+    for e in range(-30, 8):
+        alpha = mp.mpf(2) ** e / half_pi  # m * alpha close to an integer <=> m * 2^e close to a multiple of pi/2
+        # convergents p/q of alpha with q < 2^24
+        a, h0, h1, k0, k1 = alpha, 0, 1, 1, 0
+        for _ in range(40):
+            ai = int(mp.floor(a))
+            h0, h1 = h1, ai * h1 + h0
+            k0, k1 = k1, ai * k1 + k0
+            if k1 >= (1 << 24):
+                break
+            if k1 > 0:
+                x = float(k1) * 2.0 ** e
+                if 0 < x < 2147483648.0:
+                    xs.add(np.float32(x))
+            frac = a - ai
+            if frac == 0:
+                break
+            a = 1 / frac
+    x = np.array(sorted(xs), dtype=np.float32)
+    x = np.concatenate([x, -x])
+    assert x.size > 400
+    s, c = np.zeros_like(x), np.zeros_like(x)
+    O.lib().oracle_sincosf(x, s, c, x.size)
+    sr = np.array([float(mp.sin(mp.mpf(float(v)))) for v in x]).astype(np.float32)
+    cr = np.array([float(mp.cos(mp.mpf(float(v)))) for v in x]).astype(np.float32)
+    assert np.array_equal(s.view(np.uint32), sr.view(np.uint32)) and np.array_equal(c.view(np.uint32), cr.view(np.uint32))
+    # how close they get: the smallest reduced angle in the set, and its sine still carries full precision
+    rmin = min(abs(mp.mpf(float(v)) - mp.nint(mp.mpf(float(v)) / half_pi) * half_pi) for v in x if v > 0)
+    assert rmin < 1e-8
+
+
 def test_sincos_special_values(oracle):
     x = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 3.0e38], dtype=np.float32)
     s, c = np.zeros_like(x), np.zeros_like(x)
