@@ -114,6 +114,8 @@ typedef struct okenv_info {
     int32_t packed_resident;  /* 1: a resident step kernel is serving okenv_step_packed right now                    */
     int32_t packed_resident_steps; /* okenv_step_packed calls served by a resident kernel so far                     */
     int32_t packed_fallbacks; /* ... of which the resident kernel had left: redone by a launch of their own          */
+    int32_t compute_units;    /* CUs of the device as HIP reports them (256 on an MI355X in SPX mode): what the launch geometry,  */
+                              /* the lane-group rule for small populations and the tail-kernel hand-over point are sized by     */
 } okenv_info;
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */
@@ -316,7 +318,10 @@ OKENV_API int okenv_alive_count(okenv_t h, int32_t *out);
  *                      okenv_episode_compact(h, &alive, &listed); } while (alive > 0 && more steps allowed);
  *                 okenv_episode_end(h, &steps, &live);
  * Needs auto-reset off.  Any call that changes agent state from outside (set/upload/reset/step without a policy) ends the
- * episode without the end-of-episode corrections. */
+ * episode without the end-of-episode corrections.  While a controller episode is running (okenv_rollout_controller inside
+ * okenv_episode_begin / _end) okenv_tracker_begin, okenv_tracker_update and okenv_controller_set_params return OKENV_ERR_STATE:
+ * the fused rollout carries the bookkeeping itself.  A population no larger than okenv_episode_tail_limit is listed from
+ * okenv_episode_begin on (its first rollout already runs one agent per workgroup). */
 OKENV_API int okenv_episode_begin(okenv_t h);
 /* Rebuilds the list of agents the next rollouts step; *alive_out = agents with crashed_ == false (the loop's all_done test),
  * *listed_out = agents still stepped (alive ones + those that crashed in the last step taken).  Either may be NULL. */
@@ -328,6 +333,12 @@ OKENV_API int okenv_episode_tail_limit(okenv_t h, int32_t *out);
 /* *steps_out = T (steps of the reference's loop; all steps taken if somebody is still alive), *live_agent_steps_out = sum over
  * the steps of the agents that entered the step alive.  Either may be NULL. */
 OKENV_API int okenv_episode_end(okenv_t h, int32_t *steps_out, uint64_t *live_agent_steps_out);
+/* Agents whose position lies outside the raycast grid's box (the track's bounding box plus a small pad): *alive_off_grid those
+ * with crashed_ == false, *all_off_grid all of them (either may be NULL).  The crash test is lidar-only and a step can be 1.6 px
+ * long, so an agent can tunnel through both boundary polylines (Environment/CollisionChecker.cu:167-171);
+ * outside, nothing is within sensor range and only the standstill timeout (Environment.cpp:16-39) can still end it -- at speed it
+ * never does, and "until every agent has crashed" then runs into the caller's step cap.  Measurement aid; synchronises. */
+OKENV_API int okenv_off_grid_count(okenv_t h, int32_t *alive_off_grid, int32_t *all_off_grid);
 /* Agent::reset of EVERY agent to one pose (genetic_learner_sim.cpp:65-70) */
 OKENV_API int okenv_reset_all(okenv_t h, float x, float y, float rot_deg);
 /* assignScores (EvolutionaryRacer/MiscUtils.hpp:64-71): score = nearest centre-line index as float, kept on the

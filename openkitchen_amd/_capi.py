@@ -47,7 +47,7 @@ SYMBOLS = [
     "okenv_tracker_update", "okenv_step_packed",
     "okenv_controller_create", "okenv_controller_num_params", "okenv_controller_set_params", "okenv_controller_act", "okenv_rollout_controller",
     "okenv_episode_begin", "okenv_episode_compact", "okenv_episode_end", "okenv_episode_tail_limit", "okenv_work_stats",
-    "okenv_ga_scores_device", "okenv_get_stream",
+    "okenv_ga_scores_device", "okenv_get_stream", "okenv_off_grid_count",
 ]
 
 
@@ -57,7 +57,7 @@ class OkenvInfo(C.Structure):
                 ("grid_in_lds", C.c_int32), ("lds_bytes", C.c_int32), ("block_threads", C.c_int32),
                 ("grid_blocks", C.c_int32), ("lanes_per_agent", C.c_int32), ("device", C.c_int32),
                 ("agents_per_block", C.c_int32), ("packed_resident", C.c_int32), ("packed_resident_steps", C.c_int32),
-                ("packed_fallbacks", C.c_int32)]
+                ("packed_fallbacks", C.c_int32), ("compute_units", C.c_int32)]
 
 
 class OkenvError(RuntimeError):
@@ -167,6 +167,7 @@ def load(build_if_missing=True):
     L.okenv_episode_tail_limit.argtypes = [vp, C.POINTER(i32)]
     L.okenv_ga_scores_device.argtypes = [vp, C.POINTER(vp)]
     L.okenv_get_stream.argtypes = [vp, C.POINTER(vp)]
+    L.okenv_off_grid_count.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     _lib = L
     return L
 

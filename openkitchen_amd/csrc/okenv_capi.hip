@@ -84,6 +84,7 @@ struct okenv
     int         block_threads{1024}, grid_blocks{1};
     // EvolutionaryRacer state
     int      mlp_hidden{0};
+    int      cus{256}; // compute units of the device (hipDeviceAttributeMultiprocessorCount), asked once in okenv_create
     float   *d_mlp_w{nullptr}, *d_mlp_w_new{nullptr}, *d_score{nullptr}, *d_parent_score{nullptr};
     int32_t *d_nearest{nullptr}, *d_parents{nullptr}, *d_alive{nullptr};
     // Q-learning state
@@ -627,7 +628,7 @@ int launchStep(okenv *h, OkStepParams p) // (by value: the diagnostic build adds
           // whose spare lanes take intervals of the agent's rays, no phase 1 (16 rays, 64 listed agents: 9.3 against 11.8 us
           // per step; the fused MLP's steps gain nothing from it and keep their width)
             int G = h->G;
-            while (G < 64 && static_cast<long>(p.n_active) * (2L * G) <= 131072L)
+            while (G < 64 && static_cast<long>(p.n_active) * (2L * G) <= 512L * h->cus) // half of the machine's lanes, as in okenv_create
                 G *= 2;
             if (G > h->G)
             {
@@ -636,7 +637,7 @@ int launchStep(okenv *h, OkStepParams p) // (by value: the diagnostic build adds
             }
         }
         const long lanes = static_cast<long>(p.n_active) * p.G;
-        long       per   = ((((lanes + 255) / 256) + 63) / 64) * 64;
+        long       per   = ((((lanes + h->cus - 1) / h->cus) + 63) / 64) * 64;
         per              = per < 256 ? 256 : (per > 1024 ? 1024 : per);
         block            = dim3(static_cast<unsigned>(per));
         grid             = dim3(static_cast<unsigned>((lanes + per - 1) / per));
@@ -763,7 +764,7 @@ int launchStep(okenv *h, OkStepParams p) // (by value: the diagnostic build adds
 }
 
 // Longest episode list the tail kernel (okStepTailKernel) takes on this handle: one round of workgroups -- as many per CU as
-// the LDS holds, 256 CUs (measured, 32-ray MLP agents: 8.1 us per step up to 256 agents, 9.2 at 512 with two per CU, against
+// the LDS holds, times the device's compute units (256 on an MI355X in SPX mode; measured there, 32-ray MLP agents: 8.1 us per step up to 256 agents, 9.2 at 512 with two per CU, against
 // 11.2-11.8 for the cooperative kernel; a second round loses: 17 us) -- or OKENV_TAIL_MAX_AGENTS; 0: the tail kernel does not apply.
 long tailLimit(const okenv *h, const bool q_launch)
 {
@@ -773,7 +774,7 @@ long tailLimit(const okenv *h, const bool q_launch)
     const size_t   lds   = h->image_bytes + 16U + sizeof(float) * kTailLdsFloats + (q_launch ? qLdsBytes(h) + sizeof(float) * kTailQFloats : 0U);
     if (lanes > 512U || lds > kLdsBudget)
         return 0;
-    const long fit = static_cast<long>(kLdsBudget / lds) * 256L;
+    const long fit = static_cast<long>(kLdsBudget / lds) * h->cus;
     return h->tail_max_agents > 0 ? std::min<long>(h->tail_max_agents, fit) : fit;
 }
 
@@ -843,10 +844,16 @@ extern "C"
         // lanes per agent: the fan's width rounded up to a power of two -- and more when the population is far too
         // small to fill the machine: the spare lanes of an agent's group take intervals of its rays in phase 2, which
         // shortens the dependent chain of a step (11.5-13 us instead of 15.6 us per step for RL-sized populations).
-        // Kept to half of the machine's 256 x 1024 lanes so that the waves of a CU do not start competing for issue.
+        // Kept to half of the machine's lanes (compute units x 1024; the device is asked, an MI355X in CPX / DPX partition mode
+        // shows 32 / 128 of its 256 CUs) so that the waves of a CU do not start competing for issue.
+        {
+            int cus = 0;
+            OK_HIP(nullptr, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+            h->cus = cus > 0 ? cus : 256;
+        }
         h->G = pow2ceil(num_rays) > 64 ? 64 : pow2ceil(num_rays);
         const int natural_g = h->G;
-        while (h->G < 64 && static_cast<long>(num_agents) * (2L * h->G) <= 131072L)
+        while (h->G < 64 && static_cast<long>(num_agents) * (2L * h->G) <= 512L * h->cus)
             h->G *= 2;
         if (const char *env_g = std::getenv("OKENV_LANES_PER_AGENT"))
         { // tuning knob: fold the fan over fewer lanes (ray r, r+G, r+2G, ... share a lane) or spread it over more
@@ -958,9 +965,9 @@ extern "C"
         h->host_ray_deg.assign(ray_angles_deg, ray_angles_deg + num_rays);
 
         // ---- launch geometry -------------------------------------------------------------------------
-        // Spread small populations over the CUs: aim for >= 256 workgroups before growing them to 1024 lanes.
+        // Spread small populations over the CUs: aim for a workgroup on every CU before growing them to 1024 lanes.
         const long total_lanes = static_cast<long>(num_agents) * h->G;
-        long       per_block   = (total_lanes + 255) / 256;
+        long       per_block   = (total_lanes + h->cus - 1) / h->cus;
         per_block              = ((per_block + 63) / 64) * 64;
         // at least four waves per workgroup: with a handful of agents the launch is dominated by staging the ~70-90 KB track
         // image into LDS, which a single wave does four times slower (waves without an agent leave right after it)
@@ -979,11 +986,11 @@ extern "C"
         h->coop          = h->grid_mode == kGridLds && h->rays_per_lane == 1;
         if (const char *env_coop = std::getenv("OKENV_COOP")) // tuning/ablation knob: 0 = every lane walks its own ray to the end
             h->coop = h->coop && std::atoi(env_coop) != 0;
-        // up to 256 agents with a wave each (the populations of the reference's applications: 1, 15, 30, 50): one agent per
+        // up to one agent per CU with a wave each (the populations of the reference's applications: 1, 15, 30, 50): one agent per
         // workgroup, i.e. per CU -- four such waves on one CU take 7.8 us for a step, one alone 6.0 us -- and three more waves
         // that only help with the staging
         h->agents_per_block = 0;
-        if (h->coop && h->G == 64 && num_agents <= 256 && per_block == 256)
+        if (h->coop && h->G == 64 && num_agents <= h->cus && per_block == 256)
             h->agents_per_block = 1;
         if (const char *env_apb = std::getenv("OKENV_AGENTS_PER_BLOCK"))
         { // tuning knob; 0 = dense
@@ -1051,6 +1058,7 @@ extern "C"
         out->num_agents      = h->N;
         out->num_rays        = h->R;
         out->num_segments    = h->S;
+        out->compute_units   = h->cus;
         out->grid_nx         = h->grid.g.nx;
         out->grid_ny         = h->grid.g.ny;
         out->grid_cell       = h->grid.g.cell;
@@ -1726,15 +1734,26 @@ extern "C"
         return OKENV_OK;
     }
 
+    // Inside a controller episode the fused rollout carries the bookkeeping in registers and writes it back per launch: a tracker
+    // call or new parameters from outside would be double counted, lost or half applied -- refused, loudly.
+    static bool ctrlEpisodeRunning(okenv_t h)
+    {
+        return h != nullptr && h->episode && h->ep_kind == kPolicyCtrl;
+    }
+
     int okenv_tracker_begin(okenv_t h)
     {
         OK_QUIESCE(h);
+        if (ctrlEpisodeRunning(h))
+            return fail(h, OKENV_ERR_STATE, "okenv_tracker_begin: a controller episode is running (okenv_rollout_controller does the bookkeeping); okenv_episode_end first");
         return launchTracker(h, 1, "okenv_tracker_begin");
     }
 
     int okenv_tracker_update(okenv_t h)
     {
         OK_QUIESCE(h);
+        if (ctrlEpisodeRunning(h))
+            return fail(h, OKENV_ERR_STATE, "okenv_tracker_update: a controller episode is running (okenv_rollout_controller does the bookkeeping); okenv_episode_end first");
         return launchTracker(h, 0, "okenv_tracker_update");
     }
 
@@ -1774,6 +1793,8 @@ extern "C"
         OK_QUIESCE(h);
         if (!h || !params || !h->d_ctrl_params)
             return fail(h, OKENV_ERR_STATE, "okenv_controller_set_params: call okenv_controller_create first");
+        if (ctrlEpisodeRunning(h))
+            return fail(h, OKENV_ERR_STATE, "okenv_controller_set_params: a controller episode is running; okenv_episode_end first");
         OK_HIP(h, hipSetDevice(h->device));
         return copyAny(h, h->d_ctrl_params, params, sizeof(float) * static_cast<size_t>(h->N) * h->ctrl_num_params);
     }
@@ -1953,6 +1974,18 @@ extern "C"
         h->n_active = -1;
         h->ep_kind  = 0;
         h->ep_steps = 0U;
+        // A population that fits the tail kernel (the reference's 50 agents, say) is listed from the start: nobody is settled yet,
+        // so the list is 0 ... N-1 and its length is known without asking the device -- the very first rollout then already runs
+        // one agent per workgroup, each leaving with its agent, instead of the cooperative kernel that okenv_episode_compact would
+        // only replace after the first launch.
+        const bool q    = h->d_q_table != nullptr && h->d_mlp_w == nullptr;
+        const bool ctrl = h->d_ctrl_params != nullptr && h->d_mlp_w == nullptr && h->d_q_table == nullptr;
+        if (!ctrl && static_cast<long>(h->N) <= tailLimit(h, q))
+        {
+            hipLaunchKernelGGL(okEpisodeCompactKernel, dim3(1), dim3(1024), 0, h->stream, h->d_settled, h->st.crashed, h->N, h->d_active, h->d_ep_counts);
+            OK_HIP(h, hipGetLastError());
+            h->n_active = h->N;
+        }
         return OKENV_OK;
     }
 
@@ -2001,7 +2034,7 @@ extern "C"
             hipLaunchKernelGGL(okQSettleKernel, dim3(static_cast<unsigned>((static_cast<long>(h->N) * kSettleLanes + 255) / 256)), dim3(256), 0,
                                h->stream, h->st, h->d_q_table, h->d_q_state, h->d_q_action,
                                h->d_q_next_state, h->d_crash_step, h->d_ep_out, h->N, h->ep_q_seed, h->ep_q_agent_base, h->ep_q_step_base,
-                               h->ep_q_epsilon);
+                               h->ep_q_epsilon, h->R, h->q_ray[0], h->q_ray[1], h->q_ray[2], h->q_ray[3], h->q_ray[4]);
         OK_HIP(h, hipGetLastError());
         uint32_t           out[2] = {0U, 0U};
         unsigned long long live   = 0ULL;
@@ -2038,6 +2071,32 @@ extern "C"
         OK_HIP(h, hipGetLastError());
         OK_HIP(h, hipMemcpyAsync(out, d, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         OK_HIP(h, hipStreamSynchronize(h->stream));
+        return OKENV_OK;
+    }
+
+    int okenv_off_grid_count(okenv_t h, int32_t *alive_off_grid, int32_t *all_off_grid)
+    {
+        OK_QUIESCE(h);
+        if (!h)
+            return OKENV_ERR_INVALID;
+        OK_HIP(h, hipSetDevice(h->device));
+        void     *sp = nullptr;
+        const int rc = deviceScratch(h, 2U * sizeof(int), &sp);
+        if (rc != OKENV_OK)
+            return rc;
+        int *d = static_cast<int *>(sp);
+        OK_HIP(h, hipMemsetAsync(d, 0, 2U * sizeof(int), h->stream));
+        const OkGridGeom &g = h->grid.g;
+        hipLaunchKernelGGL(okOffGridCountKernel, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, h->st.pos_x, h->st.pos_y, h->st.crashed, h->N,
+                           g.x0, g.y0, g.x1, g.y1, d);
+        OK_HIP(h, hipGetLastError());
+        int host[2] = {0, 0};
+        OK_HIP(h, hipMemcpyAsync(host, d, 2U * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        if (alive_off_grid)
+            *alive_off_grid = host[0];
+        if (all_off_grid)
+            *all_off_grid = host[1];
         return OKENV_OK;
     }
 

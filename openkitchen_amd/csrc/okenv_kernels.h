@@ -2400,6 +2400,25 @@ __global__ void okAliveCountKernel(const uint8_t *crashed, int N, int *out)
         atomicAdd(out, __popcll(m));
 }
 
+// Agents whose position lies outside the grid box (the track's bounding box plus the builder's pad): out[0] counts those with
+// crashed_ == false, out[1] all of them.  An agent out there casts no ray that can reach a segment within range once it is more
+// than a sensor range away, can therefore never crash by lidar (it tunnelled through both boundary
+// polylines) and only the standstill timeout can still end it.
+__global__ void okOffGridCountKernel(const float *pos_x, const float *pos_y, const uint8_t *crashed, int N, float x0, float y0, float x1,
+                                     float y1, int *out)
+{
+    const int  i   = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool off = i < N && !(pos_x[i] >= x0 && pos_x[i] <= x1 && pos_y[i] >= y0 && pos_y[i] <= y1); // NaN poses count as off the grid
+    const unsigned long long m_all   = __ballot(off);
+    const unsigned long long m_alive = __ballot(off && crashed[i] == 0);
+    if ((threadIdx.x & 63) == 0 && m_all)
+    {
+        atomicAdd(out + 1, __popcll(m_all));
+        if (m_alive)
+            atomicAdd(out, __popcll(m_alive));
+    }
+}
+
 // The kNumParents = 5 best agents (Mating.hpp:115-119): descending score, ties to the lower index.  One workgroup.
 __global__ void __launch_bounds__(1024) okGaTopKernel(const float *score, int N, int32_t *parents, float *parent_score, int K)
 {
@@ -2605,7 +2624,7 @@ constexpr int kSettleLanes = 16;
 
 __global__ void okQSettleKernel(OkDeviceState st, float *q_table, const int32_t *q_state, int32_t *q_action, const int32_t *q_next_state,
                                 const uint32_t *crash_step, const uint32_t *T_ptr, int N, uint32_t seed, uint32_t agent_base,
-                                uint32_t step_base, float epsilon)
+                                uint32_t step_base, float epsilon, int R, int r0, int r1, int r2, int r3, int r4)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int a   = gid / kSettleLanes, l = gid % kSettleLanes;
@@ -2616,8 +2635,18 @@ __global__ void okQSettleKernel(OkDeviceState st, float *q_table, const int32_t 
         return;
     float    *table = q_table + static_cast<size_t>(a) * (OK_Q_STATES * OK_Q_ACTIONS);
     const int sc    = q_state[a];
-    // an agent that was crashed when the episode began (c == 0) sees the state of the initial observation as its next state
-    const int  sn   = c == 0U ? sc : q_next_state[a];
+    // An agent that was crashed when the episode began (c == 0) never wrote q_next_state: what it sees as its next state in every
+    // step is discretizeState() of its stale observation (q_racer_sim.cpp:173: the rays keep the hit points of the crash step, the
+    // origin no longer moves), i.e. of the distances its last step left behind.  Right after okenv_q_begin_episode that IS q_state;
+    // after a crash in an earlier okenv_rollout_q call outside an episode it is not (q_state stays the state before the crash, :177).
+    int sn;
+    if (c == 0U)
+    {
+        const float *d = st.dist + static_cast<long>(a) * R;
+        sn             = ok_q_bin(d[r0]) + 3 * ok_q_bin(d[r1]) + 9 * ok_q_bin(d[r2]) + 27 * ok_q_bin(d[r3]) + 81 * ok_q_bin(d[r4]);
+    }
+    else
+        sn = q_next_state[a];
     const bool same = sn == sc;
     float c0 = table[sc * OK_Q_ACTIONS + 0], c1 = table[sc * OK_Q_ACTIONS + 1], c2 = table[sc * OK_Q_ACTIONS + 2];
     const float n0 = table[sn * OK_Q_ACTIONS + 0], n1 = table[sn * OK_Q_ACTIONS + 1], n2 = table[sn * OK_Q_ACTIONS + 2];

@@ -321,6 +321,12 @@ class BatchedEnvironment:
         capi.check(self._L.okenv_episode_end(self._h, C.byref(steps), C.byref(live)), self._h)
         return steps.value, live.value
 
+    def off_grid_count(self):
+        """(alive, all) agents outside the raycast grid's box: escaped through the boundaries, nothing left in sensor range."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        capi.check(self._L.okenv_off_grid_count(self._h, C.byref(a), C.byref(b)), self._h)
+        return int(a.value), int(b.value)
+
     def reset_all(self, x, y, rot_deg):
         capi.check(self._L.okenv_reset_all(self._h, float(x), float(y), float(rot_deg)), self._h)
 

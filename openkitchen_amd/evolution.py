@@ -39,7 +39,7 @@ class EvolutionaryRacer:
         e.step(1)  # initial observation (genetic_learner_sim.cpp:75)
         e.episode_begin()
         tail = e.episode_tail_limit()
-        steps, listed = 0, e.N
+        steps, listed, alive = 0, e.N, e.N
         budget = self.max_steps - 1
         while steps < budget:
             # once the list is short enough for one agent per workgroup, a workgroup leaves when its agent is done: ask for all the
@@ -52,6 +52,7 @@ class EvolutionaryRacer:
                 break
         loop_steps, self.live_agent_steps = e.episode_end()
         self.live_agent_steps += e.N  # everybody takes the initial step
+        self.alive_at_end = int(alive)  # > 0 only when the step cap ended the loop
         return 1 + loop_steps
 
     def run_generation(self):
@@ -76,8 +77,12 @@ class EvolutionaryRacer:
         self.env.sync()
         t2 = time.perf_counter()
         stats = torch.stack([local.max(), local.mean(), colony.max(), colony.mean()]).tolist()  # four scalars leave the device
+        # (outside the timed parts) who ended the generation where: agents outside the raycast grid's box tunnelled through both
+        # boundaries and cannot crash any more -- if one of them is alive, it is what ran the loop into the step cap
+        off_alive, off_all = self.env.off_grid_count() if hasattr(self.env, "off_grid_count") else (0, 0)
         rec = {"generation": self.generation, "steps": steps, "live_agent_steps": int(self.live_agent_steps), "rollout_s": t1 - t0,
-               "select_mate_s": t2 - t1, "all_gather_s": tg,
+               "select_mate_s": t2 - t1, "all_gather_s": tg, "alive_at_end": self.alive_at_end, "off_grid_alive": off_alive,
+               "off_grid_agents": off_all,
                "island_best": stats[0], "island_mean": stats[1], "colony_best": stats[2], "colony_mean": stats[3],
                "parents": [int(v) for v in parents]}
         self.history.append(rec)

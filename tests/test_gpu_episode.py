@@ -225,6 +225,50 @@ def test_q_episode_equals_reference_loop(gpu, oracle, track_name, N, R, spl):
     dev.close()
 
 
+@pytest.mark.parametrize("track_name,N,R,pre", [("Austin", 48, 5, 60), ("Silverstone", 96, 16, 35), ("Spa", 64, 16, 90)])
+def test_q_episode_with_agents_crashed_in_earlier_steps_outside_an_episode(gpu, oracle, track_name, N, R, pre):
+    """Agents that crash in plain okenv_rollout_q steps BEFORE okenv_episode_begin keep the state before the crash as their
+    current state (q_racer_sim.cpp:177) while every later step's next state is discretizeState() of their stale rays (:173) -- in
+    general another table row.  The episode settles their -200 updates at its end and must take max Q from that row."""
+    t, dev, orc, oq = make_q(gpu, oracle, track_name, N, R)
+    seed, eps = 77, np.float32(0.9)
+    dev.q_begin_episode(3)
+    oq.begin_episode(3)
+    for s in range(pre):  # plain per-step calls, no episode: the step kernel itself makes the crashed agents' updates here
+        dev.rollout_q(1, float(eps), seed, 0, s)
+        oq.rollout(1, float(eps), seed, 0, s)
+    crashed = orc.snapshot()["crashed"].astype(bool)
+    assert 0 < crashed.sum() < N
+    st, _, _ = oq.state()
+    d = orc.snapshot()["dist"].reshape(N, R)
+    from_stale = np.zeros(N, dtype=np.int64)
+    rays = [int(np.argmin(np.abs(gpu.default_ray_fan(R) - a))) for a in (-70, -30, 0, 30, 70)] if R != 5 else list(range(5))
+    for i, r in enumerate(rays):
+        from_stale += np.where(d[:, r] < 5, 0, np.where(d[:, r] < 10, 1, 2)) * 3 ** i
+    assert (from_stale[crashed] != np.asarray(st)[crashed]).any()  # the case the assumption "next state == stored state" gets wrong
+    want_steps = 0
+    while want_steps < 900:
+        oq.rollout(1, float(eps), seed, 0, pre + want_steps)
+        want_steps += 1
+        if oracle.lib().oracle_env_alive_count(orc.h) == 0:
+            break
+    dev.episode_begin()
+    taken = 0
+    while taken < 900:
+        dev.rollout_q(40, float(eps), seed, 0, pre + taken)
+        taken += 40
+        alive, _ = dev.episode_compact()
+        if alive == 0:
+            break
+    steps, _ = dev.episode_end()
+    assert steps == want_steps
+    assert_same_state(dev.snapshot(), orc.snapshot(), "after the episode")
+    assert np.array_equal(bits(dev.q_table()), bits(oq.table()))
+    for got, want in zip(dev.q_state(), oq.state()):
+        assert np.array_equal(got, want)
+    dev.close()
+
+
 def test_q_episode_short_list_gets_wider_lane_groups(gpu, oracle, monkeypatch):
     monkeypatch.setenv("OKENV_TAIL_MAX_AGENTS", "0")   # (the cooperative kernel's treatment of short lists; the tail kernel is the default)
     _q_short_list(gpu, oracle, monkeypatch)

@@ -198,3 +198,53 @@ def test_c5_full_size_episode_window_equals_oracle(gpu, oracle):
             assert np.array_equal(got[BASE:BASE + W], want)
         eps = eps - np.float32(0.05)
     dev.close()
+
+
+def test_c4_island_generation_that_runs_into_the_step_cap(gpu, oracle):
+    """BASELINE config 4's island (8192 x 32 rays, Spa, the benchmark's seed) as the benchmark runs it: the second timed generation
+    takes all 4000 steps -- not because anybody laps the track but because ONE agent has tunnelled through both boundary polylines
+    (the crash test is lidar-only and a step can be 1.6 px long: SURVEY.md appendix A.4, CollisionChecker.cu:167-171) and drives
+    on outside at full speed, where nothing is within sensor range and the standstill timeout never fires.  That regime -- thousands
+    of steps of an agent off the grid, thousands of pixels away -- is replayed on the oracle for the survivor and the generation's
+    best scorers, from the device's state at the generation's start (DisplacementStats carry over from the generations before), one
+    Environment::step at a time to the cap, and compared bit for bit."""
+    import torch
+    from openkitchen_amd.evolution import EvolutionaryRacer
+    N, R, seed = 8192, 32, 1234
+    t = gpu.Track("Spa")
+    env = gpu.BatchedEnvironment.from_track(t, N, R, device=0)
+    ga = EvolutionaryRacer(env, t, hidden=30, seed=seed, agent_base=0, max_steps=4000, steps_per_launch=100, device=torch.device("cuda", 0))
+    recs = [ga.run_generation() for _ in range(2)]
+    assert [r["steps"] for r in recs] == [804, 1005] and all(r["alive_at_end"] == 0 and r["off_grid_alive"] == 0 for r in recs)
+    env.reset_all(*ga.start)            # the state generation 2 starts from (its own reset_all repeats this one)
+    s0, w0 = env.snapshot(), env.policy_weights().copy()
+    rec = ga.run_generation()
+    s1 = env.snapshot()
+    assert rec["steps"] == 4000 and rec["alive_at_end"] == 1 and rec["off_grid_alive"] == 1 and rec["off_grid_agents"] >= 1
+    survivors = np.flatnonzero(s1["crashed"] == 0)
+    assert survivors.size == 1
+    a = int(survivors[0])
+    seg = t.segments.reshape(-1, 4)
+    far = max(float(s1["pos_x"][a]) - seg[:, [0, 2]].max(), seg[:, [0, 2]].min() - float(s1["pos_x"][a]),
+              float(s1["pos_y"][a]) - seg[:, [1, 3]].max(), seg[:, [1, 3]].min() - float(s1["pos_y"][a]))
+    assert far > 1000 and s1["speed"][a] == 100.0      # thousands of pixels beyond the track's box, flat out
+    score = ga._fitness.cpu().numpy()
+    ids = np.unique(np.concatenate([survivors, np.argsort(-score, kind="stable")[:31], np.arange(8)]))
+    K = ids.size
+    fan = gpu.default_ray_fan(R)
+    orc = oracle.OracleEnv(t.segments, K, R, fan, (t.x, t.y, t.heading))
+    names = gpu.capi.FIELD_NAMES
+    for f in range(19):
+        v = s0[names[f]]
+        orc.set(f, v.reshape(N, R)[ids] if f in gpu.capi.PER_RAY else v[ids])
+    og = oracle.OracleGA(orc, 30, seed, 0)
+    og.set_weights(w0[ids])
+    orc.step(1)                          # the initial observation (genetic_learner_sim.cpp:75)
+    for _ in range(rec["steps"] - 1):    # the reference's loop to the cap, crashed agents included
+        og.rollout_policy(1)
+    want = orc.snapshot()
+    got = {k: (v.reshape(N, R)[ids] if v.size == N * R else v[ids]) for k, v in s1.items()}
+    assert_same_state(got, want, "the survivor and the best scorers after 4000 steps")
+    assert np.array_equal(score[ids], og.scores())
+    assert (want["crashed"] == 0).sum() == 1
+    env.close()

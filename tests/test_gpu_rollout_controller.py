@@ -146,3 +146,22 @@ def test_rollout_controller_refusals(gpu, oracle):
         with pytest.raises(RuntimeError, match="too wide"):
             dev.rollout_controller(1)
     dev.close()
+    # while a controller episode is running its bookkeeping and parameters are the rollout's: outside calls are refused
+    dev = gpu.BatchedEnvironment.from_track(t, 16, ray_angles_deg=RAYS)
+    n_params = dev.controller_create(16)
+    dev.tracker_create(1)
+    params = np.zeros((16, n_params), dtype=np.float32)
+    dev.controller_set_params(params)
+    dev.step(1)
+    dev.tracker_begin()
+    dev.episode_begin()
+    dev.tracker_update()  # no controller rollout yet: still the caller's loop
+    dev.rollout_controller(3)
+    for call, name in ((dev.tracker_begin, "okenv_tracker_begin"), (dev.tracker_update, "okenv_tracker_update"),
+                       (lambda: dev.controller_set_params(params), "okenv_controller_set_params")):
+        with pytest.raises(RuntimeError, match=name + ": a controller episode is running"):
+            call()
+    dev.episode_end()
+    dev.tracker_update()
+    dev.controller_set_params(params)
+    dev.close()

@@ -69,7 +69,10 @@ if "SQ_INSTS_VALU" in agg:
 if "FETCH_SIZE" in agg and "WRITE_SIZE" in agg and summary:
     import hashlib
     hh = hashlib.sha256()
-    for rel in ("openkitchen_amd/csrc/okenv_kernels.h", "openkitchen_amd/csrc/ok_raycast.h", "openkitchen_amd/csrc/ok_grid.h"):
+    import sys
+    sys.path.insert(0, "$GRAFT_REPO_ROOT")
+    from bench import KERNEL_SOURCES  # the one list of files the hash covers
+    for rel in KERNEL_SOURCES:
         hh.update(open("$GRAFT_REPO_ROOT/" + rel, "rb").read())
     tj = {"kernel_source_sha256": hh.hexdigest(),  # bench.py reports these counters only while the kernel's sources still hash to this
           "source": "profiles/%s_SUMMARY.txt (rocprofv3 --pmc passes of bench.py --steps 1000 --steps-per-launch 100 --headline-only)" % "$TAG",
