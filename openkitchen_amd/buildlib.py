@@ -48,7 +48,7 @@ def needs_build():
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = sources() + HEADERS + [os.path.join(ROOT, "include", "Environment", f)
-                                  for f in os.listdir(os.path.join(ROOT, "include", "Environment"))]
+                                  for f in os.listdir(os.path.join(ROOT, "include", "Environment")) if f.endswith(".h")]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
