@@ -8,7 +8,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "libokenv_oracle.so")
+# OKENV_SANITIZE=1 (tests/test_sanitizers.py, in a child process with libasan preloaded): the ASan + UBSan build of the same source
+SANITIZE = os.environ.get("OKENV_SANITIZE") == "1"
+SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-O1"]
+ORACLE_SO = os.path.join(ORACLE_DIR, "libokenv_oracle_san.so" if SANITIZE else "libokenv_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libokref.so")
 TRACK_DIR = os.path.join(ROOT, "openkitchen_amd", "tracks")
 
@@ -37,8 +40,8 @@ FIELD_NAMES = ["pos_x", "pos_y", "rot", "speed", "acc", "thr", "steer", "mode", 
 
 
 def build_oracle(with_ref=True):
-    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
-    if with_ref and os.path.isdir("/root/reference/Environment"):
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR] + (["san"] if SANITIZE else []), check=True)
+    if with_ref and not SANITIZE and os.path.isdir("/root/reference/Environment"):
         subprocess.run(["make", "-s", "-C", ORACLE_DIR, "ref"], check=True)
         if os.path.exists(os.path.join(ROOT, "openkitchen_amd", "libokenv.so")):
             subprocess.run(["make", "-s", "-C", ORACLE_DIR, "refbind"], check=True)

@@ -18,8 +18,9 @@ def gridcheck():
     src = os.path.join(HERE, "cpp", "grid_check.cpp")
     out_dir = os.path.join(HERE, "cpp", "_build")
     os.makedirs(out_dir, exist_ok=True)
-    so = os.path.join(out_dir, "libgridcheck.so")
-    subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src], check=True)
+    so = os.path.join(out_dir, "libgridcheck_san.so" if O.SANITIZE else "libgridcheck.so")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared"] + (O.SAN_FLAGS if O.SANITIZE else []) + ["-o", so, src],
+                   check=True)
     G = C.CDLL(so)
     G.gridcheck_cast.argtypes = [O.f32p, C.c_int, C.c_float, O.f32p, O.f32p, O.f32p, C.c_int, O.f32p, O.u32p, O.u32p, O.i32p, C.c_int, O.u32p]
     G.gridcheck_first_hit_update.argtypes = [C.c_int] + [O.f32p] * 11

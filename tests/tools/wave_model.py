@@ -14,12 +14,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _oracle as O  # noqa: E402
 
-SO = os.path.join(ROOT, "tools", "_build", "libwavemodel.so")
+SO = os.path.join(ROOT, "tools", "_build", "libwavemodel_san.so" if O.SANITIZE else "libwavemodel.so")
 
 
 def build():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC"] + (O.SAN_FLAGS if O.SANITIZE else []) +
+                   ["-I", os.path.join(ROOT, "include"),
                     "-I", os.path.join(ROOT, "openkitchen_amd", "csrc"), "-o", SO, os.path.join(ROOT, "tests", "tools", "wave_model.cpp")], check=True)
     L = C.CDLL(SO)
     f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
