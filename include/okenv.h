@@ -116,6 +116,9 @@ typedef struct okenv_info {
     int32_t packed_fallbacks; /* ... of which the resident kernel had left: redone by a launch of their own          */
     int32_t compute_units;    /* CUs of the device as HIP reports them (256 on an MI355X in SPX mode): what the launch geometry,  */
                               /* the lane-group rule for small populations and the tail-kernel hand-over point are sized by     */
+    int32_t front_back_bytes; /* > 0: the segment set is split (ok_grid.h): bytes of the [front | back] images the cooperative     */
+                              /* kernel stages instead of the combined image; 0: no split (not a track, or OKENV_FRONT_BACK=0)     */
+    int32_t back_segments;    /* segments in the back image: looked at only by rays whose origin is not certified / ambiguous walks */
 } okenv_info;
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */

@@ -49,6 +49,20 @@
  * instruction) on x86-64 -- the same bits either way.  The translation units are still compiled -ffp-contract=off: nothing is
  * fused that does not say so here. */
 #define OK_FMA(a, b, c) __builtin_fma((a), (b), (c))
+/* A double constant of the polynomials below.  On the device it is made opaque and pinned to a scalar register pair: hipcc would
+ * otherwise materialise each one in a VECTOR register pair (v_fmac_f64 wants its addend there), hoist all of them out of the
+ * kernels' step loops and keep them alive across the raycast -- 22 more VGPRs in every step kernel, scratch spills in the policy
+ * ones (profiles/r4/kernel_resource_usage.txt).  As scalar operands of v_fma_f64 they cost s_mov's and no vector registers.  The
+ * value is untouched: same bits on both sides. */
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ inline __attribute__((always_inline)) double ok_konst(double c)
+{
+    asm("" : "+s"(c));
+    return c;
+}
+#else
+#define ok_konst(c) (c)
+#endif
 
 /*
  * sin and cos of an fp32 angle [rad], from an fp64 evaluation rounded once to fp32 (round 4's form; rounds 1-3 used a
@@ -77,24 +91,24 @@ OK_HD void ok_sincosf(float x, float *s_out, float *c_out)
             return;
         }
     }
-    const double q = OK_RINT(xd * 0x1.45f306dc9c883p-1); /* 2/pi */
-    double r = OK_FMA(-q, 0x1.921fb54442d18p+0, xd);     /* P1 = 1.5707963267948966    */
-    r = OK_FMA(-q, 0x1.1a62633145c07p-54, r);            /* P2 = 6.123233995736766e-17 */
+    const double q = OK_RINT(xd * ok_konst(0x1.45f306dc9c883p-1)); /* 2/pi */
+    double r = OK_FMA(-q, ok_konst(0x1.921fb54442d18p+0), xd);     /* P1 = 1.5707963267948966    */
+    r = OK_FMA(-q, ok_konst(0x1.1a62633145c07p-54), r);            /* P2 = 6.123233995736766e-17 */
     const int n = ((int)q) & 3;                          /* quadrant; |q| < 1.4e9 fits an int */
     const double z = r * r;
-    double ps = 0x1.5e01d1798c2b3p-33;              /*  1.5916480269048027e-10 */
-    ps = OK_FMA(ps, z, -0x1.ae5ff116c8d06p-26);     /* -2.505110882200661e-08  */
-    ps = OK_FMA(ps, z, 0x1.71de377d84985p-19);      /*  2.755731599143529e-06  */
-    ps = OK_FMA(ps, z, -0x1.a01a019e70424p-13);     /* -1.9841269836543094e-04 */
-    ps = OK_FMA(ps, z, 0x1.1111111110b60p-7);       /*  8.333333333330806e-03  */
-    ps = OK_FMA(ps, z, -0x1.5555555555555p-3);      /* -1.6666666666666666e-01 */
+    double ps = ok_konst(0x1.5e01d1798c2b3p-33);              /*  1.5916480269048027e-10 */
+    ps = OK_FMA(ps, z, ok_konst(-0x1.ae5ff116c8d06p-26));     /* -2.505110882200661e-08  */
+    ps = OK_FMA(ps, z, ok_konst(0x1.71de377d84985p-19));      /*  2.755731599143529e-06  */
+    ps = OK_FMA(ps, z, ok_konst(-0x1.a01a019e70424p-13));     /* -1.9841269836543094e-04 */
+    ps = OK_FMA(ps, z, ok_konst(0x1.1111111110b60p-7));       /*  8.333333333330806e-03  */
+    ps = OK_FMA(ps, z, ok_konst(-0x1.5555555555555p-3));      /* -1.6666666666666666e-01 */
     const double sr = OK_FMA(r * z, ps, r);
-    double pc = 0x1.1bfd9695386eap-29;              /*  2.0663034153592203e-09 */
-    pc = OK_FMA(pc, z, -0x1.27e0dd327adbcp-22);     /* -2.75558210165445e-07   */
-    pc = OK_FMA(pc, z, 0x1.a019fc4c6ed87p-16);      /*  2.4801582456863223e-05 */
-    pc = OK_FMA(pc, z, -0x1.6c16c168f930cp-10);     /* -1.3888888881805088e-03 */
-    pc = OK_FMA(pc, z, 0x1.5555555554001p-5);       /*  4.166666666662878e-02  */
-    pc = OK_FMA(pc, z, -0x1.ffffffffffffap-2);      /* -4.9999999999999967e-01 */
+    double pc = ok_konst(0x1.1bfd9695386eap-29);              /*  2.0663034153592203e-09 */
+    pc = OK_FMA(pc, z, ok_konst(-0x1.27e0dd327adbcp-22));     /* -2.75558210165445e-07   */
+    pc = OK_FMA(pc, z, ok_konst(0x1.a019fc4c6ed87p-16));      /*  2.4801582456863223e-05 */
+    pc = OK_FMA(pc, z, ok_konst(-0x1.6c16c168f930cp-10));     /* -1.3888888881805088e-03 */
+    pc = OK_FMA(pc, z, ok_konst(0x1.5555555554001p-5));       /*  4.166666666662878e-02  */
+    pc = OK_FMA(pc, z, ok_konst(-0x1.ffffffffffffap-2));      /* -4.9999999999999967e-01 */
     const double cr = OK_FMA(z, pc, 1.0);
     double sv, cv;
     if (n == 0) { sv = sr; cv = cr; }
@@ -253,17 +267,17 @@ OK_HD float ok_tanhf(const float x)
     if (!(ax >= 0.000244140625)) /* |x| < 2^-12: x^3/3 is below half an ulp of x; NaN takes this exit too and stays NaN */
         return x;
     const double y = -2.0 * (ax < 20.0 ? ax : 20.0); /* tanh(20) is 1 to 17 digits: larger arguments change nothing */
-    const double n = OK_RINT(y * 0x1.71547652b82fep+0); /* 1 / ln 2 */
-    double r = OK_FMA(-n, 0x1.62e42fefa39efp-1, y);     /* L1 = 0.6931471805599453     */
-    r = OK_FMA(-n, 0x1.abc9e3b39803fp-56, r);           /* L2 = 2.3190468138462996e-17 */
-    double p = 0x1.28809b1a1156ep-22;           /* 2.7613934750302004e-07 */
-    p = OK_FMA(p, r, 0x1.72c7b3ac3a215p-19);    /* 2.7625269095508424e-06 */
-    p = OK_FMA(p, r, 0x1.a019c964743c8p-16);    /* 2.4801536157973374e-05 */
-    p = OK_FMA(p, r, 0x1.a019ad41ef162p-13);    /* 1.9841208455585307e-04 */
-    p = OK_FMA(p, r, 0x1.6c16c1739cf9cp-10);    /* 1.388888890599716e-03  */
-    p = OK_FMA(p, r, 0x1.1111111c5b16fp-7);     /* 8.333333353868181e-03  */
-    p = OK_FMA(p, r, 0x1.5555555554ca3p-5);     /* 4.166666666665122e-02  */
-    p = OK_FMA(p, r, 0x1.5555555553b3cp-3);     /* 1.6666666666648122e-01 */
+    const double n = OK_RINT(y * ok_konst(0x1.71547652b82fep+0)); /* 1 / ln 2 */
+    double r = OK_FMA(-n, ok_konst(0x1.62e42fefa39efp-1), y);     /* L1 = 0.6931471805599453     */
+    r = OK_FMA(-n, ok_konst(0x1.abc9e3b39803fp-56), r);           /* L2 = 2.3190468138462996e-17 */
+    double p = ok_konst(0x1.28809b1a1156ep-22);           /* 2.7613934750302004e-07 */
+    p = OK_FMA(p, r, ok_konst(0x1.72c7b3ac3a215p-19));    /* 2.7625269095508424e-06 */
+    p = OK_FMA(p, r, ok_konst(0x1.a019c964743c8p-16));    /* 2.4801536157973374e-05 */
+    p = OK_FMA(p, r, ok_konst(0x1.a019ad41ef162p-13));    /* 1.9841208455585307e-04 */
+    p = OK_FMA(p, r, ok_konst(0x1.6c16c1739cf9cp-10));    /* 1.388888890599716e-03  */
+    p = OK_FMA(p, r, ok_konst(0x1.1111111c5b16fp-7));     /* 8.333333353868181e-03  */
+    p = OK_FMA(p, r, ok_konst(0x1.5555555554ca3p-5));     /* 4.166666666665122e-02  */
+    p = OK_FMA(p, r, ok_konst(0x1.5555555553b3cp-3));     /* 1.6666666666648122e-01 */
     p = OK_FMA(p, r, 0.5);
     const double m = OK_FMA(r * r, p, r); /* expm1(r) */
     union { uint64_t u; double d; } two_n; /* 2^n, n in [-58, 0] */

@@ -57,7 +57,8 @@ class OkenvInfo(C.Structure):
                 ("grid_in_lds", C.c_int32), ("lds_bytes", C.c_int32), ("block_threads", C.c_int32),
                 ("grid_blocks", C.c_int32), ("lanes_per_agent", C.c_int32), ("device", C.c_int32),
                 ("agents_per_block", C.c_int32), ("packed_resident", C.c_int32), ("packed_resident_steps", C.c_int32),
-                ("packed_fallbacks", C.c_int32), ("compute_units", C.c_int32)]
+                ("packed_fallbacks", C.c_int32), ("compute_units", C.c_int32), ("front_back_bytes", C.c_int32),
+                ("back_segments", C.c_int32)]
 
 
 class OkenvError(RuntimeError):

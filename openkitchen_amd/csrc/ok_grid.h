@@ -12,6 +12,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "ok_raycast.h"
@@ -87,7 +89,11 @@ inline bool finiteSeg(const OkSeg &s)
 } // namespace okgrid
 
 // Builds the grid with the given cell edge.  `max_cells` bounds nx*ny (the cell edge is enlarged if needed).
-inline OkGridHost okBuildGrid(const OkSeg *segs, const size_t num_segments, float cell, const size_t max_cells = 1U << 20)
+// `include` (optional, one byte per segment): only segments with a non-zero byte are registered -- the box, the margin and the
+// cells are still those of ALL segments, so grids built over subsets of one segment set share their geometry cell for cell
+// (the front / back images below).
+inline OkGridHost okBuildGrid(const OkSeg *segs, const size_t num_segments, float cell, const size_t max_cells = 1U << 20,
+                              const uint8_t *include = nullptr)
 {
     OkGridHost out;
     double     minx = 1e300, miny = 1e300, maxx = -1e300, maxy = -1e300, maxabs = 0.0;
@@ -180,6 +186,8 @@ inline OkGridHost okBuildGrid(const OkSeg *segs, const size_t num_segments, floa
             const OkSeg &s = segs[i];
             if (!okgrid::finiteSeg(s))
                 continue; // can never produce a valid hit: every comparison on NaN/Inf quotients fails
+            if (include != nullptr && include[i] == 0)
+                continue;
             int ix0, ix1, iy0, iy1;
             cellRange(s, ix0, ix1, iy0, iy1);
             for (int iy = iy0; iy <= iy1; ++iy)
@@ -440,4 +448,338 @@ inline OkGridHost okBuildGridAuto(const OkSeg *segs,
     }
     *fits_lds = false;
     return okBuildGrid(segs, num_segments, requested > 0.F ? requested : OKGRID_DEFAULT_CELL);
+}
+
+// ---- front / back split of the segment set (round 4) ----------------------------------------------------------------------
+//
+// Half of the points a ray meets belong to the OUTER boundary polylines, which run 3 px behind the inner ones and can be the
+// first hit only for an agent that has already left the track.  The split below lets a step look at them only when that can
+// matter, and keeps the result the reference's bits:
+//
+//   chi       The closed chains among the segments that stand for the inner boundaries (F) define chi(p) = parity of the number
+//             of F crossings of any ray from p to infinity.  chi is constant on the components of the plane minus F and flips
+//             across every F segment -- for ANY closed polygonal chains, simple or not (the inner boundaries of the config
+//             tracks do cross themselves in tight corners).
+//   back      A segment b outside F is a BACK segment when both its end points have chi = 0 and it keeps a distance of at least
+//             kBackClearance from every F segment (so chi = 0 all along it, with room for every rounding in the tests).
+//             Everything else -- F itself, outer pieces that cross an inner boundary or come close to it, segments that belong
+//             to no closed chain -- is a FRONT segment.
+//   claim     A ray whose origin has chi = 1 meets no back segment before its first F crossing: up to that crossing it runs where
+//             chi = 1, and no back segment has a point there.  Its first hit over ALL segments is therefore its first hit over
+//             the front segments, provided (i) chi(origin) = 1 is established robustly (ok_raycast.h: okOriginChi, from the
+//             precomputed chi of a reference point of the origin's cell and the parity of the F segments the straight line from
+//             there to the origin crosses), and (ii) no F crossing was MISSED by the fp32 test for rounding reasons (the walk
+//             reports candidates it rejected by less than the error bounds e_s / e_t below as ambiguous).  A ray for which either
+//             fails walks the back image too: min over front and back = min over all segments, as always.
+//   cells     chi is established per step from the origin's cell: a cell is certifiable when every front segment registered in
+//             it belongs to F, its front slots fit one chunk, and one of four reference points keeps >= kRefClearance from F.
+//
+// Which chains are "the inner boundaries" cannot be read off a bare segment array: the reference's TrackSegments order
+// (Environment/TrackSegments.cu:11-39: runs LI, LO, RI, RO of n/4 - 1 segments, then the four closers) is assumed and CHECKED
+// (closed chains found by bit-equal end points); any other input simply gets no split.  The choice only decides how much is
+// gained, never what is computed.
+struct OkFrontBack
+{
+    bool                 ok{false};
+    std::vector<uint8_t> front, back; // per segment
+    std::vector<uint8_t> chi_def;     // per segment: member of F
+    std::vector<uint8_t> cell_flags;  // per cell: bit 0 certifiable, bit 1 chi(reference point), bits 2-3 reference point code
+    float                e_s{0.F}, e_t{0.F}, t12{0.F}, t34{0.F};
+    size_t               n_f{0}, n_back{0}, n_front_other{0}, n_cells_cert{0}, n_cells_with_front{0};
+};
+#define OKFB_CELL_CERT 1U
+#define OKFB_CELL_CHI 2U
+#define OKFB_HDR_SHIFT 27 // the cell flags sit in bits 27..30 of the front image's header word w0
+
+namespace okgrid
+{
+constexpr double kBackClearance = 0.5; // px
+constexpr double kRefClearance  = 1.0; // px
+
+inline double pointSegDist2(const double px, const double py, const double ax, const double ay, const double bx, const double by)
+{
+    const double dx = bx - ax, dy = by - ay;
+    const double l2 = dx * dx + dy * dy;
+    double       t  = l2 > 0.0 ? ((px - ax) * dx + (py - ay) * dy) / l2 : 0.0;
+    t               = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+    const double qx = ax + t * dx - px, qy = ay + t * dy - py;
+    return qx * qx + qy * qy;
+}
+inline double orient(const double ax, const double ay, const double bx, const double by, const double cx, const double cy)
+{
+    return (bx - ax) * (cy - ay) - (by - ay) * (cx - ax);
+}
+inline double segSegDist2(const OkSeg &a, const OkSeg &b)
+{
+    const double o1 = orient(a.x1, a.y1, a.x2, a.y2, b.x1, b.y1), o2 = orient(a.x1, a.y1, a.x2, a.y2, b.x2, b.y2);
+    const double o3 = orient(b.x1, b.y1, b.x2, b.y2, a.x1, a.y1), o4 = orient(b.x1, b.y1, b.x2, b.y2, a.x2, a.y2);
+    if (((o1 > 0.0) != (o2 > 0.0) || o1 == 0.0 || o2 == 0.0) && ((o3 > 0.0) != (o4 > 0.0) || o3 == 0.0 || o4 == 0.0))
+        return 0.0; // they cross or touch (collinear overlaps are caught by the point distances below as 0 too)
+    double d = pointSegDist2(a.x1, a.y1, b.x1, b.y1, b.x2, b.y2);
+    d        = std::fmin(d, pointSegDist2(a.x2, a.y2, b.x1, b.y1, b.x2, b.y2));
+    d        = std::fmin(d, pointSegDist2(b.x1, b.y1, a.x1, a.y1, a.x2, a.y2));
+    d        = std::fmin(d, pointSegDist2(b.x2, b.y2, a.x1, a.y1, a.x2, a.y2));
+    return d;
+}
+// chi of point p: crossings of the horizontal ray from p to +x with the chi-defining segments (half-open rule on y, so a
+// vertex on the ray's line counts once).  *robust = false when p lies (numerically) on one of the segments' lines where it matters.
+inline int chiOf(const OkSeg *segs, const size_t n, const uint8_t *chi_def, const double px, const double py, bool *robust)
+{
+    int parity = 0;
+    for (size_t i = 0; i < n; ++i)
+    {
+        if (!chi_def[i])
+            continue;
+        const OkSeg &s = segs[i];
+        const bool   up = (s.y1 <= py) && (s.y2 > py), down = (s.y2 <= py) && (s.y1 > py);
+        if (!up && !down)
+            continue;
+        const double c = orient(s.x1, s.y1, s.x2, s.y2, px, py);
+        if (std::fabs(c) < 1e-7)
+            *robust = false;
+        if ((up && c > 0.0) || (down && c < 0.0))
+            parity ^= 1;
+    }
+    return parity;
+}
+// the four reference point candidates of a cell, in the fp32 arithmetic the device repeats (ok_raycast.h: okCellRefPoint)
+inline void cellRefPoint(const OkGridGeom &g, const int ix, const int iy, const unsigned code, float *rx, float *ry)
+{
+    const float fx = (code & 1U) ? 0.75F : 0.25F, fy = (code & 2U) ? 0.75F : 0.25F;
+    *rx            = g.x0 + (static_cast<float>(ix) + fx) * g.cell;
+    *ry            = g.y0 + (static_cast<float>(iy) + fy) * g.cell;
+}
+} // namespace okgrid
+
+inline OkFrontBack okClassifyFrontBack(const OkSeg *segs, const size_t n, const OkGridHost &grid, const float max_seg_len)
+{
+    OkFrontBack fb;
+    fb.front.assign(n, 1);
+    fb.back.assign(n, 0);
+    fb.chi_def.assign(n, 0);
+    fb.cell_flags.assign(grid.numCells(), 0);
+    if (n < 16 || (n % 4U) != 0U)
+        return fb;
+    for (size_t i = 0; i < n; ++i)
+        if (!okgrid::finiteSeg(segs[i]))
+            return fb; // (a set with non-finite segments is somebody's test, not a track)
+    // ---- closed chains: next[i] = the one segment that starts, bit for bit, where i ends ----
+    auto key = [](const float x, const float y) {
+        uint32_t ux, uy;
+        std::memcpy(&ux, &x, 4);
+        std::memcpy(&uy, &y, 4);
+        return (static_cast<uint64_t>(ux) << 32) | uy;
+    };
+    std::vector<std::pair<uint64_t, uint32_t>> starts(n);
+    for (size_t i = 0; i < n; ++i)
+        starts[i] = {key(segs[i].x1, segs[i].y1), static_cast<uint32_t>(i)};
+    std::sort(starts.begin(), starts.end());
+    std::vector<int32_t> next(n, -1), indeg(n, 0);
+    for (size_t i = 0; i < n; ++i)
+    {
+        const uint64_t k  = key(segs[i].x2, segs[i].y2);
+        auto           lo = std::lower_bound(starts.begin(), starts.end(), std::make_pair(k, 0U));
+        if (lo != starts.end() && lo->first == k && (lo + 1 == starts.end() || (lo + 1)->first != k))
+        {
+            next[i] = static_cast<int32_t>(lo->second);
+            ++indeg[lo->second];
+        }
+    }
+    std::vector<int32_t> cyc(n, -1), stamp(n, -1);
+    int32_t              n_cyc = 0;
+    for (size_t i = 0; i < n; ++i)
+    {
+        if (stamp[i] >= 0)
+            continue;
+        int32_t j = static_cast<int32_t>(i);
+        while (j >= 0 && stamp[j] < 0)
+        {
+            stamp[j] = static_cast<int32_t>(i);
+            j        = next[j];
+        }
+        if (j >= 0 && stamp[j] == static_cast<int32_t>(i))
+        { // closed back into this walk: j .. j is a cycle; clean if every member has exactly one predecessor
+            bool    clean = true;
+            int32_t m     = j;
+            do
+            {
+                clean = clean && indeg[m] == 1;
+                m     = next[m];
+            } while (m != j);
+            if (clean)
+            {
+                do
+                {
+                    cyc[m] = n_cyc;
+                    m      = next[m];
+                } while (m != j);
+                ++n_cyc;
+            }
+        }
+    }
+    // ---- F: the chains of segment 0 (LI) and of segment 2 * (n/4 - 1) (RI) in TrackSegments order ----
+    const size_t  run = n / 4U - 1U;
+    const int32_t c_li = cyc[0], c_ri = cyc[2U * run];
+    if (c_li < 0 || c_ri < 0)
+        return fb;
+    for (size_t i = 0; i < n; ++i)
+        if (cyc[i] == c_li || cyc[i] == c_ri)
+        {
+            fb.chi_def[i] = 1;
+            ++fb.n_f;
+        }
+    // ---- back segments: chi = 0 at both ends, clear of F ----
+    const OkGridGeom &g = grid.g;
+    const double      reach = okgrid::kBackClearance + grid.margin;
+    for (size_t i = 0; i < n; ++i)
+    {
+        if (fb.chi_def[i])
+            continue;
+        const OkSeg &b = segs[i];
+        bool         robust = true;
+        if (okgrid::chiOf(segs, n, fb.chi_def.data(), b.x1, b.y1, &robust) != 0 || okgrid::chiOf(segs, n, fb.chi_def.data(), b.x2, b.y2, &robust) != 0 ||
+            !robust)
+        {
+            ++fb.n_front_other;
+            continue;
+        }
+        // F segments near b: those registered in the cells b's inflated bounding box overlaps
+        int ix0 = static_cast<int>(std::floor((std::fmin(b.x1, b.x2) - reach - g.x0) / g.cell)) - 1;
+        int ix1 = static_cast<int>(std::floor((std::fmax(b.x1, b.x2) + reach - g.x0) / g.cell)) + 1;
+        int iy0 = static_cast<int>(std::floor((std::fmin(b.y1, b.y2) - reach - g.y0) / g.cell)) - 1;
+        int iy1 = static_cast<int>(std::floor((std::fmax(b.y1, b.y2) + reach - g.y0) / g.cell)) + 1;
+        ix0     = ix0 < 0 ? 0 : ix0;
+        iy0     = iy0 < 0 ? 0 : iy0;
+        ix1     = ix1 >= g.nx ? g.nx - 1 : ix1;
+        iy1     = iy1 >= g.ny ? g.ny - 1 : iy1;
+        bool clear = true;
+        for (int iy = iy0; iy <= iy1 && clear; ++iy)
+            for (int ix = ix0; ix <= ix1 && clear; ++ix)
+            {
+                const size_t c = static_cast<size_t>(iy) * g.nx + ix;
+                for (uint32_t k = grid.start[c]; k < grid.start[c + 1]; ++k)
+                {
+                    const uint32_t f = grid.refs[k];
+                    if (fb.chi_def[f] && okgrid::segSegDist2(b, segs[f]) < okgrid::kBackClearance * okgrid::kBackClearance)
+                    {
+                        clear = false;
+                        break;
+                    }
+                }
+            }
+        if (clear)
+        {
+            fb.back[i]  = 1;
+            fb.front[i] = 0;
+            ++fb.n_back;
+        }
+        else
+            ++fb.n_front_other;
+    }
+    if (fb.n_back * 8U < n) // next to nothing to leave for later: not worth a second image
+        return fb;
+    // ---- error bounds of the walk's exact test and of the origin test (u = 2^-24; derivations in ok_raycast.h) ----
+    const double u = std::ldexp(1.0, -24);
+    const double A = 200.0 + 2.0 * 1.4143 * g.cell + max_seg_len + 2.0 * grid.margin; // farthest point from an origin a walk can meet
+    const double L = max_seg_len;
+    const double D = 1.4143 * g.cell + 2.0 * grid.margin + L; // farthest F point from a point of the origin's cell ... that matters
+    fb.e_s         = static_cast<float>(16.0 * u * A);
+    fb.e_t         = static_cast<float>(16.0 * u * A * std::fmax(L, 1.0));
+    fb.t12         = static_cast<float>(16.0 * u * std::fmax(L, 1.0) * D);
+    fb.t34         = static_cast<float>(16.0 * u * D * D);
+    // ---- cells: certifiable?  chi of the reference point ----
+    for (int iy = 0; iy < g.ny; ++iy)
+        for (int ix = 0; ix < g.nx; ++ix)
+        {
+            const size_t c         = static_cast<size_t>(iy) * g.nx + ix;
+            bool         only_f    = true;
+            bool         any_front = false;
+            for (uint32_t k = grid.start[c]; k < grid.start[c + 1]; ++k)
+            {
+                const uint32_t sidx = grid.refs[k];
+                if (fb.front[sidx])
+                {
+                    any_front = true;
+                    only_f    = only_f && fb.chi_def[sidx] != 0;
+                }
+            }
+            if (any_front)
+                ++fb.n_cells_with_front;
+            if (!only_f)
+                continue;
+            for (unsigned code = 0; code < 4U; ++code)
+            {
+                float rx, ry;
+                okgrid::cellRefPoint(g, ix, iy, code, &rx, &ry);
+                bool good = true;
+                // clear of every F segment around, and clearly off the supporting line of every F segment registered in the cell
+                // (the device's d1 then needs no tolerance test of its own)
+                for (int jy = std::max(0, iy - 1); jy <= std::min(g.ny - 1, iy + 1) && good; ++jy)
+                    for (int jx = std::max(0, ix - 1); jx <= std::min(g.nx - 1, ix + 1) && good; ++jx)
+                    {
+                        const size_t cc = static_cast<size_t>(jy) * g.nx + jx;
+                        for (uint32_t k = grid.start[cc]; k < grid.start[cc + 1]; ++k)
+                        {
+                            const OkSeg &f = segs[grid.refs[k]];
+                            if (!fb.chi_def[grid.refs[k]])
+                                continue;
+                            if (okgrid::pointSegDist2(rx, ry, f.x1, f.y1, f.x2, f.y2) < okgrid::kRefClearance * okgrid::kRefClearance)
+                                good = false;
+                            else if (cc == c && std::fabs(okgrid::orient(f.x1, f.y1, f.x2, f.y2, rx, ry)) < 64.0 * fb.t12)
+                                good = false;
+                            if (!good)
+                                break;
+                        }
+                    }
+                if (!good)
+                    continue;
+                bool      robust = true;
+                const int chi    = okgrid::chiOf(segs, n, fb.chi_def.data(), rx, ry, &robust);
+                if (!robust)
+                    continue;
+                fb.cell_flags[c] = static_cast<uint8_t>(OKFB_CELL_CERT | (chi ? OKFB_CELL_CHI : 0U) | (code << 2));
+                ++fb.n_cells_cert;
+                break;
+            }
+        }
+    fb.ok = true;
+    return fb;
+}
+
+// The two images of a split segment set over ONE grid geometry: `front` carries the cell flags in its headers.
+struct OkFrontBackImages
+{
+    bool        ok{false};
+    OkGridHost  grid_front, grid_back;
+    OkPolyImage front, back;
+};
+
+inline OkFrontBackImages okBuildFrontBackImages(const OkSeg *segs, const size_t n, const OkGridHost &grid, OkFrontBack &fb)
+{
+    OkFrontBackImages out;
+    if (!fb.ok)
+        return out;
+    out.grid_front = okBuildGrid(segs, n, grid.g.cell, 1U << 20, fb.front.data());
+    out.grid_back  = okBuildGrid(segs, n, grid.g.cell, 1U << 20, fb.back.data());
+    // same geometry by construction (the box is that of all finite segments, the cell edge is given)
+    if (out.grid_front.g.nx != grid.g.nx || out.grid_front.g.ny != grid.g.ny || out.grid_back.g.nx != grid.g.nx || out.grid_back.g.ny != grid.g.ny ||
+        out.grid_front.g.x0 != grid.g.x0 || out.grid_front.g.y0 != grid.g.y0 || out.grid_front.g.cell != grid.g.cell)
+        return out;
+    out.front = okBuildPolyImage(segs, n, out.grid_front);
+    out.back  = okBuildPolyImage(segs, n, out.grid_back);
+    if (!out.front.ok || !out.back.ok)
+        return out;
+    OkCellHdr *hdr = reinterpret_cast<OkCellHdr *>(out.front.bytes.data() + out.front.off_hdr);
+    fb.n_cells_cert = 0;
+    for (size_t c = 0; c < grid.numCells(); ++c)
+    {
+        uint32_t flags = fb.cell_flags[c];
+        if (((hdr[c].w0 >> (OKPOLY_IDX_BITS + 6)) & 1U) != 0U) // the cell's front slots continue in a second chunk: not certifiable
+            flags = 0U;
+        fb.cell_flags[c] = static_cast<uint8_t>(flags);
+        fb.n_cells_cert += (flags & OKFB_CELL_CERT) ? 1U : 0U;
+        hdr[c].w0 |= flags << OKFB_HDR_SHIFT;
+    }
+    out.ok = true;
+    return out;
 }

@@ -101,6 +101,10 @@ struct OkPolyView
     const OkPoint   *slots;
     const OkCellHdr *hdr;
     float            side_tol;
+    // front / back split only (ok_grid.h, okClassifyFrontBack): absolute error bounds of the exact test's folded numerators
+    // fs (e_s) and ft (e_t) against their exact values -- a candidate rejected by less than that may be a crossing the fp32
+    // arithmetic missed and is reported as ambiguous
+    float            e_s, e_t, e_s_over_e_t;
 };
 #define OKPOLY_IDX_BITS 20
 #define OKPOLY_IDX_MASK 0xFFFFFU
@@ -339,13 +343,25 @@ OKRC_HD int32_t okMax3i(const int32_t a, const int32_t b, const int32_t c)
 // The range tests run on the bit patterns: non-negative floats order like their bits read as integers, NaNs and
 // infinities sort above every finite value, and "0 < x <= y" for y >= 0 is the single unsigned comparison
 // bits(x) - 1 < bits(y) (x = +0 wraps to the top, negative x and NaNs have bits above every non-negative finite y).
+//
+// kAmb (front / back split): *amb tells whether the candidate may be a crossing of the ray with this segment, in the exact
+// geometry of the same fp32 coordinates, that the fp32 test MISSED.  With fs*, ft*, d* the exact values of the folded numerators and |denom|, an exact crossing at
+// t* in (0, min_t) has 0 <= fs* <= d* and ft* > 0; the computed values differ from them by at most e_s, e_t (ok_grid.h:
+// |fs - fs*| <= 6uA, |d - d*| <= 6uL, |ft - ft*| <= 8uAL with u = 2^-24, A the farthest a point can lie from an origin, L the
+// longest segment; e_s = 16uA, e_t = 16uAL).  So a rejected candidate with fs < -e_s, fs > |denom| + e_s or ft < -e_t holds no such
+// crossing: a missed crossing has fs within e_s of 0 or of |denom|, or |ft| <= e_t, and that is what is flagged (taken or not,
+// in range or not: the superset costs nothing); every candidate on the irregular or near-parallel path is flagged as well.
+template <bool kAmb = false>
 OKRC_HD float ok_first_hit_update(const float   ox,
                                   const float   oy,
                                   const float   rdx,
                                   const float   rdy,
                                   const OkPoint a,
                                   const OkPoint b,
-                                  const float   min_t)
+                                  const float   min_t,
+                                  const float   e_s = 0.F,
+                                  const float   e_t = 0.F,
+                                  float        *amb = nullptr) // kAmb: running minimum of the candidates' distance from "missable"
 {
     constexpr int32_t kBitsLo  = 0x1E3CE508; // 1e-20f
     constexpr int32_t kBitsHi  = 0x501502F9; // 1e10f
@@ -368,6 +384,17 @@ OKRC_HD float ok_first_hit_update(const float   ox,
     const int32_t lo = okMin3i(bas, bat, static_cast<int32_t>(bd) - (kBitsEps - kBitsLo));
     const int32_t hi = okMax3i(bas, bat, static_cast<int32_t>(bd));
     float         result = min_t;
+    // kAmb: how far the candidate is from the two ways a crossing can be missed -- fs within e_s of 0 or of |denom| (the ray
+    // passes a segment's end within rounding) and |ft| within e_t (the origin lies on the segment's line within rounding) -- as ONE
+    // running minimum: near = min(| |fs - h| - h |, |ft| * e_s / e_t) with h = |denom| / 2 is <= e_s exactly when one of the two
+    // holds.  Whether the candidate was taken, or lies beyond the current first hit, is not looked at: flagging a few more costs
+    // nothing.  Five plain VALU operations, no lane masks.
+    if (kAmb)
+    {
+        const float fs = okFromBits(bfs), ft = okFromBits(bft), h = 0.5F * okFromBits(bd);
+        const float ws = __builtin_fabsf(__builtin_fabsf(fs - h) - h);
+        *amb           = __builtin_fminf(*amb, __builtin_fminf(ws, __builtin_fabsf(ft) * e_t)); // (e_t here: the factor e_s / e_t)
+    }
     if (lo >= kBitsLo && hi < kBitsHi)
     {
         const float lim = (min_t * 1.00001F) * okFromBits(bd);
@@ -377,27 +404,34 @@ OKRC_HD float ok_first_hit_update(const float   ox,
             result        = (t <= min_t) ? t : min_t;
         }
     }
-    else if (!(okFromBits(bd) < OK_PARALLEL_EPS))
-    { // the reference's own sequence (CollisionChecker.cu:23-33)
-        const float t = num_t / denom;
-        if ((t >= 0.0F) && (t <= min_t))
-        {
-            const float sq = num_s / denom;
-            if ((sq >= 0.0F) && (sq <= 1.0F))
-                result = t;
+    else
+    {
+        if (kAmb)
+            *amb = 0.0F; // tiny, huge or non-finite values, a near-parallel pair whose ends are not clearly on one side: cannot tell
+        if (!(okFromBits(bd) < OK_PARALLEL_EPS))
+        { // the reference's own sequence (CollisionChecker.cu:23-33)
+            const float t = num_t / denom;
+            if ((t >= 0.0F) && (t <= min_t))
+            {
+                const float sq = num_s / denom;
+                if ((sq >= 0.0F) && (sq <= 1.0F))
+                    result = t;
+            }
         }
     }
     return result;
 }
 
 // exact test of the registered segment (slot k, slot k+1); returns the updated first-hit parameter
+template <bool kAmb = false>
 OKRC_HD float okExactSlot(const OkPolyView &v,
                           const uint32_t    k,
                           const float       ox,
                           const float       oy,
                           const float       rdx,
                           const float       rdy,
-                          const float       min_t)
+                          const float       min_t,
+                          float            *amb = nullptr)
 {
     const OkPoint a = v.slots[k];
     const OkPoint b = v.slots[k + 1];
@@ -405,13 +439,88 @@ OKRC_HD float okExactSlot(const OkPolyView &v,
     float t;
     return ok_ray_segment(ox, oy, rdx, rdy, a.x, a.y, b.x, b.y, min_t, t) ? t : min_t;
 #else
-    return ok_first_hit_update(ox, oy, rdx, rdy, a, b, min_t);
+    return ok_first_hit_update<kAmb>(ox, oy, rdx, rdy, a, b, min_t, v.e_s, v.e_s_over_e_t, amb);
 #endif
 }
 
 OKRC_HD uint32_t okCountTrailingZeros(const uint32_t x)
 {
     return static_cast<uint32_t>(__builtin_ctz(x));
+}
+
+// ---- front / back split: is the ray origin on the side of the inner boundaries where back segments cannot come first? --------
+// (ok_grid.h, okClassifyFrontBack, has the argument.)  chi(origin) = chi(reference point of the origin's cell) XOR parity of the F
+// segments that the straight line from the reference point to the origin crosses.  Both points lie in the cell, so only segments
+// registered in the cell can be crossed, and in a certifiable cell every front segment IS an F segment: the pairs of the cell's
+// (single) front chunk are all there is to test.
+#define OKFB_HDR_SHIFT_RC 27 // = OKFB_HDR_SHIFT in ok_grid.h: cell flags in the front image's header word w0
+#define OKFB_RC_CERT 1U
+#define OKFB_RC_CHI 2U
+
+// reference point `code` (0..3) of cell (ix, iy): the arithmetic ok_grid.h's okgrid::cellRefPoint repeats on the host
+OKRC_HD void okCellRefPoint(const OkGridGeom &g, const int ix, const int iy, const uint32_t code, float *rx, float *ry)
+{
+    const float fx = (code & 1U) ? 0.75F : 0.25F, fy = (code & 2U) ? 0.75F : 0.25F;
+    *rx            = g.x0 + (static_cast<float>(ix) + fx) * g.cell;
+    *ry            = g.y0 + (static_cast<float>(iy) + fy) * g.cell;
+}
+
+// One F segment (a, b) against the line from r to o: 0 = certainly not crossed, 1 = certainly crossed, 2 = cannot tell.
+//   d1, d2: r and o relative to the line through a, b;  d3, d4: a and b relative to the line through r, o.
+// Crossed <=> (d1, d2 of opposite signs) and (d3, d4 of opposite signs); not crossed <=> one of the pairs has equal signs.  Each
+// statement is only made when the values involved exceed their error bound (t12 for d1 / d2 -- and the host has picked r so that
+// |d1| is 64 times that -- t34 for d3 / d4: 16 u L D and 16 u D^2 against roundings of ~5 u L D and ~5 u D^2, D = the farthest an
+// F point registered in the cell can lie from a point of the cell, ok_grid.h).
+OKRC_HD int okChiPairClass(const OkPoint a, const OkPoint b, const float rx, const float ry, const float ox, const float oy, const float t12, const float t34)
+{
+    const float sx = b.x - a.x, sy = b.y - a.y;
+    const float d1 = sx * (ry - a.y) - sy * (rx - a.x);
+    const float d2 = sx * (oy - a.y) - sy * (ox - a.x);
+    const float wx = ox - rx, wy = oy - ry;
+    const float d3 = wx * (a.y - ry) - wy * (a.x - rx);
+    const float d4 = wx * (b.y - ry) - wy * (b.x - rx);
+    const bool  c12 = __builtin_fabsf(d1) > t12 && __builtin_fabsf(d2) > t12; // both signs are the true ones
+    const bool  c34 = __builtin_fabsf(d3) > t34 && __builtin_fabsf(d4) > t34;
+    const bool  opp12 = (d1 > 0.F) != (d2 > 0.F), opp34 = (d3 > 0.F) != (d4 > 0.F);
+    if ((c12 && !opp12) || (c34 && !opp34))
+        return 0;
+    if (c12 && c34) // (opp12 && opp34)
+        return 1;
+    return 2;
+}
+
+// The test as one thread makes it (the CPU tests; the kernels deal the pairs to the lanes of the agent's group: okenv_kernels.h,
+// okOriginChiGroup -- same classes, same parity).  Returns 1 when chi(origin) = 1 is certain, 0 otherwise (chi = 0, an origin
+// outside the grid, a cell that is not certifiable, any pair that cannot be told).
+OKRC_HD int okOriginChiScalar(const OkPolyView &front, const float ox, const float oy, const float t12, const float t34)
+{
+    const OkGridGeom &g = front.g;
+    if (!(ox >= g.x0 && ox <= g.x1 && oy >= g.y0 && oy <= g.y1)) // (NaN poses too)
+        return 0;
+    int ix = (int)__builtin_floorf((ox - g.x0) * g.inv_cell);
+    int iy = (int)__builtin_floorf((oy - g.y0) * g.inv_cell);
+    ix     = ix < 0 ? 0 : (ix >= g.nx ? g.nx - 1 : ix);
+    iy     = iy < 0 ? 0 : (iy >= g.ny ? g.ny - 1 : iy);
+    const OkCellHdr hc    = front.hdr[iy * g.nx + ix];
+    const uint32_t  flags = hc.w0 >> OKFB_HDR_SHIFT_RC;
+    if ((flags & OKFB_RC_CERT) == 0U)
+        return 0;
+    float rx, ry;
+    okCellRefPoint(g, ix, iy, (flags >> 2) & 3U, &rx, &ry);
+    const uint32_t k0 = hc.w0 & OKPOLY_IDX_MASK;
+    const uint32_t n  = (hc.w0 >> OKPOLY_IDX_BITS) & OKPOLY_N_MASK;
+    const uint32_t n8 = (n + 7U) & ~7U;
+    uint32_t       parity = (flags & OKFB_RC_CHI) ? 1U : 0U;
+    for (uint32_t j = 0; j + 1U < n; ++j)
+    { // pair (slot j, slot j + 1) is a segment when the break bit of slot j + 1 is clear (bit n8 - 1 - (j + 1))
+        if ((hc.brk >> (n8 - 2U - j)) & 1U)
+            continue;
+        const int cls = okChiPairClass(front.slots[k0 + j], front.slots[k0 + j + 1U], rx, ry, ox, oy, t12, t34);
+        if (cls == 2)
+            return 0;
+        parity ^= static_cast<uint32_t>(cls);
+    }
+    return static_cast<int>(parity);
 }
 
 // What a walk over part of a ray reports.
@@ -421,6 +530,7 @@ struct OkIntervalResult
     float t_reached;  // the ray has been covered up to this parameter
     bool  conclusive; // min_t is the ray's final first-hit value: a hit inside the covered part, or the walk reached
                       // the sensor range / left the grid
+    bool  amb;        // kAmb walks: some candidate was rejected within rounding (ok_first_hit_update): a crossing may have been missed
 };
 
 struct alignas(16) OkVec4 // 16-byte aligned load unit (ds_read_b128): two consecutive slots
@@ -494,7 +604,9 @@ OKRC_HD uint32_t okShiftInSign(const uint32_t acc, const float d)
 // (by more than kOwnEps, far above the rounding of the crossing parameters, far below a cell): each cell of a ray is then
 // processed by the one walk in whose interval the ray enters it, instead of by two.  (A 25 px interval of a ray touches two or
 // three 24 px cells; the first of them is the neighbour's last.)  Must be false for the walk that starts a ray.
-template <bool kCount>
+// min_t0: a first hit already known from elsewhere (the front image's, when this walk covers the back image): the walk starts
+// with it, so it ends as soon as the cells up to that parameter are covered and reports min(min_t0, what it finds).
+template <bool kCount, bool kAmb = false>
 OKRC_HD OkIntervalResult ok_cast_poly_interval(const OkPolyView &v,
                                                const float       ox,
                                                const float       oy,
@@ -506,7 +618,8 @@ OKRC_HD OkIntervalResult ok_cast_poly_interval(const OkPolyView &v,
                                                uint32_t         *cells,
                                                uint32_t         *points,
                                                unsigned long long *prof = nullptr,
-                                               const bool        skip_unowned_start = false)
+                                               const bool        skip_unowned_start = false,
+                                               const float       min_t0 = OK_SENSOR_RANGE)
 {
     const OkGridGeom &g = v.g;
     OKRC_PROF_BEGIN();
@@ -526,7 +639,7 @@ OKRC_HD OkIntervalResult ok_cast_poly_interval(const OkPolyView &v,
     const bool in_x   = !par_x || (ox >= g.x0 && ox <= g.x1);
     const bool in_y   = !par_y || (oy >= g.y0 && oy <= g.y1);
     if (!(in_x && in_y && (t_in <= t_out))) // the interval misses the grid box (also rejects NaN poses)
-        return {OK_SENSOR_RANGE, OK_SENSOR_RANGE, true};
+        return {min_t0, OK_SENSOR_RANGE, true, false};
     const float px = ox + t_in * rdx;
     const float py = oy + t_in * rdy;
     int         ix = (int)__builtin_floorf((px - g.x0) * g.inv_cell);
@@ -551,7 +664,8 @@ OKRC_HD OkIntervalResult ok_cast_poly_interval(const OkPolyView &v,
     const float tol    = v.side_tol;
     const float c_ray  = __builtin_fmaf(ox, rdy, -(oy * rdx)); // side(p) = p.x * dy - p.y * dx - c_ray
     const float neg_dx = -rdx;
-    float       min_t  = OK_SENSOR_RANGE;
+    float       min_t  = min_t0;
+    float       amb    = OKRC_INF; // kAmb: running minimum of the candidates' distance from being missable (ok_first_hit_update)
 
     // What leaving the current cell will mean is known when the cell is entered, except for hits found inside it:
     //   t_exit             parameter at which the ray leaves the cell
@@ -593,9 +707,9 @@ OKRC_HD OkIntervalResult ok_cast_poly_interval(const OkPolyView &v,
             left_x -= go_x ? 1 : 0;
             left_y -= go_x ? 0 : 1;
             if (t_out <= te || (left_x | left_y) < 0) // the range, the grid box or the grid ends inside that cell
-                return {OK_SENSOR_RANGE, OK_SENSOR_RANGE, true};
+                return {min_t0, OK_SENSOR_RANGE, true, false};
             if (te >= t_b) // (an interval shorter than its start cell: every cell it touches is the previous walk's)
-                return {OK_SENSOR_RANGE, te, false};
+                return {min_t0, te, false, false};
             cell += go_x ? lin_x : lin_y;
             tmax_x = go_x ? tmax_x + tdel_x : tmax_x;
             tmax_y = go_x ? tmax_y : tmax_y + tdel_y;
@@ -656,7 +770,7 @@ OKRC_HD OkIntervalResult ok_cast_poly_interval(const OkPolyView &v,
             cand &= ~(0x80000000U >> z);
             if (kCount)
                 *tests += 1;
-            min_t = okExactSlot(v, top - (31U - z), ox, oy, rdx, rdy, min_t);
+            min_t = okExactSlot<kAmb>(v, top - (31U - z), ox, oy, rdx, rdy, min_t, &amb);
         }
         OKRC_PROF(3);
         if (((hc.w0 >> (OKPOLY_IDX_BITS + 6)) & 1U) != 0U)
@@ -681,7 +795,7 @@ OKRC_HD OkIntervalResult ok_cast_poly_interval(const OkPolyView &v,
     // leave == 0 only if the guard ran out, which cannot happen; treat it like leaving the grid
     const float t_reached  = (leave == 1 || leave == 2) ? t_exit : OK_SENSOR_RANGE;
     const bool  conclusive = leave != 2;
-    return {min_t, t_reached, conclusive};
+    return {min_t, t_reached, conclusive, kAmb && amb <= v.e_s};
 }
 
 // First-hit parameter of one whole ray, compact form.

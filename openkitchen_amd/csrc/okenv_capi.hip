@@ -84,6 +84,13 @@ struct okenv
     int         block_threads{1024}, grid_blocks{1};
     // EvolutionaryRacer state
     int      mlp_hidden{0};
+    // front / back split of the segment set (ok_grid.h): classification, the two images, and their copy on the device as one blob
+    // [front | back]; fb_ok: the cooperative kernel's non-packed launches use it
+    OkFrontBack       fbc;
+    OkFrontBackImages fbi;
+    bool              fb_ok{false};
+    uint8_t          *d_image_fb{nullptr};
+    size_t            fb_bytes{0}, fb_back_off{0};
     int      cus{256}; // compute units of the device (hipDeviceAttributeMultiprocessorCount), asked once in okenv_create
     float   *d_mlp_w{nullptr}, *d_mlp_w_new{nullptr}, *d_score{nullptr}, *d_parent_score{nullptr};
     int32_t *d_nearest{nullptr}, *d_parents{nullptr}, *d_alive{nullptr};
@@ -714,8 +721,29 @@ int launchStep(okenv *h, OkStepParams p) // (by value: the diagnostic build adds
     case kGridLds:
         if (h->coop)
         {
-            const size_t   lds = coopLdsBytes(h);
-            const uint32_t off = static_cast<uint32_t>(h->image_bytes);
+            size_t   lds = coopLdsBytes(h);
+            uint32_t off = static_cast<uint32_t>(h->image_bytes);
+            // the front / back split, for the instantiations that have it (not the packed exchange, not the direct dealing of small
+            // populations: those keep the combined image) and when everything else the launch stages still fits behind it
+            const bool has_extra = p.action_source == kActionsQLearning || p.action_source == kActionsController;
+            if (h->fb_ok && p.rec_in == nullptr && !(policy == kPolicyNone && !has_extra && directIntervals(h)) &&
+                h->fb_bytes + kCoopLdsExtra + (has_extra ? qLdsBytes(h) : 0U) <= kLdsBudget)
+            {
+                p.image            = h->d_image_fb;
+                p.image_bytes      = static_cast<uint32_t>(h->fb_bytes);
+                p.off_hdr          = static_cast<uint32_t>(h->fbi.front.off_hdr);
+                p.side_tol         = h->fbi.front.side_tol;
+                p.fb               = 1U;
+                p.fb_back_off      = static_cast<uint32_t>(h->fb_back_off);
+                p.fb_back_off_hdr  = static_cast<uint32_t>(h->fb_back_off + h->fbi.back.off_hdr);
+                p.fb_back_side_tol = h->fbi.back.side_tol;
+                p.fb_e_s           = h->fbc.e_s;
+                p.fb_e_t           = h->fbc.e_t;
+                p.fb_t12           = h->fbc.t12;
+                p.fb_t34           = h->fbc.t34;
+                off                = static_cast<uint32_t>(h->fb_bytes);
+                lds                = h->fb_bytes + kCoopLdsExtra;
+            }
             if (p.action_source == kActionsQLearning)
                 hipLaunchKernelGGL(okStepCoopKernel<kPolicyQ>, grid, block, lds + qLdsBytes(h), h->stream, p, off, phase1);
             else if (p.action_source == kActionsController)
@@ -899,6 +927,25 @@ extern "C"
                 return fail(nullptr, rc, h->last_error);
             h->d_image = dimg;
             OK_HIP(nullptr, hipMemcpyAsync(dimg, img.data(), h->image_bytes, hipMemcpyHostToDevice, h->stream));
+            // The front / back split (ok_grid.h): the outer boundary polylines in an image of their own, walked only by the rays
+            // that need it.  OKENV_FRONT_BACK=0 keeps every launch on the combined image (ablation; same results).
+            const char *env_fb = std::getenv("OKENV_FRONT_BACK");
+            if (env_fb == nullptr || std::atoi(env_fb) != 0)
+            {
+                h->fbc = okClassifyFrontBack(segs, static_cast<size_t>(num_segments), h->grid, h->poly.max_seg_len);
+                h->fbi = okBuildFrontBackImages(segs, static_cast<size_t>(num_segments), h->grid, h->fbc);
+                if (h->fbi.ok && h->fbi.front.bytes.size() + h->fbi.back.bytes.size() <= kLdsBudget - kLdsReserve)
+                {
+                    h->fb_back_off = h->fbi.front.bytes.size(); // (a multiple of 16: both parts of an image are 16-byte aligned)
+                    h->fb_bytes    = h->fb_back_off + h->fbi.back.bytes.size();
+                    if ((rc = devAlloc(h, &h->d_image_fb, h->fb_bytes)) != OKENV_OK)
+                        return fail(nullptr, rc, h->last_error);
+                    OK_HIP(nullptr, hipMemcpyAsync(h->d_image_fb, h->fbi.front.bytes.data(), h->fb_back_off, hipMemcpyHostToDevice, h->stream));
+                    OK_HIP(nullptr, hipMemcpyAsync(h->d_image_fb + h->fb_back_off, h->fbi.back.bytes.data(), h->fbi.back.bytes.size(), hipMemcpyHostToDevice,
+                                                   h->stream));
+                    h->fb_ok = true;
+                }
+            }
             OK_HIP(nullptr, hipStreamSynchronize(h->stream));
             const int lds_plain = static_cast<int>(h->image_bytes), lds_coop = static_cast<int>(coopLdsBytes(h));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepKernel<kGridLds, kPolicyNone>),
@@ -906,15 +953,15 @@ extern "C"
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepKernel<kGridLds, kPolicyMlp>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_plain));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, true>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, true, true>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, false, false, false, 64, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, false, false, false, 64>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, false, false, true>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, true, false, true>),
@@ -922,13 +969,13 @@ extern "C"
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, true, true, true>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyMlp>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyQ>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyCtrl>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyMlp, false, false, false, 32>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepTailKernel<kPolicyMlp, 32>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepTailKernel<kPolicyMlp, 15>),
@@ -1059,6 +1106,8 @@ extern "C"
         out->num_rays        = h->R;
         out->num_segments    = h->S;
         out->compute_units   = h->cus;
+        out->front_back_bytes = h->fb_ok ? static_cast<int32_t>(h->fb_bytes) : 0;
+        out->back_segments    = h->fb_ok ? static_cast<int32_t>(h->fbc.n_back) : 0;
         out->grid_nx         = h->grid.g.nx;
         out->grid_ny         = h->grid.g.ny;
         out->grid_cell       = h->grid.g.cell;

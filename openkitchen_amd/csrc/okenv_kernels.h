@@ -85,6 +85,12 @@ struct OkStepParams
     uint32_t       image_bytes, off_hdr;
     float          side_tol;
     OkGridGeom     geom;
+    // front / back split (ok_grid.h: okClassifyFrontBack), cooperative kernel only: fb != 0 means `image` holds [front image |
+    // back image] over the one geometry -- off_hdr / side_tol above are the front image's, the back image's slots start at
+    // fb_back_off and its headers at fb_back_off_hdr (bytes from `image`) -- and a step walks the back image only for rays that
+    // need it.  e_s / e_t: the exact test's ambiguity bounds; t12 / t34: those of the origin test (ok_raycast.h).
+    uint32_t       fb, fb_back_off, fb_back_off_hdr;
+    float          fb_back_side_tol, fb_e_s, fb_e_t, fb_t12, fb_t34;
     // wide (global-memory) form
     const OkSeg    *g_segs;
     const uint32_t *g_refs32;
@@ -849,8 +855,67 @@ __device__ __forceinline__ OkPolyView okSetupView(const OkStepParams &p, unsigne
         view.slots    = reinterpret_cast<const OkPoint *>(lds);
         view.hdr      = reinterpret_cast<const OkCellHdr *>(lds + p.off_hdr);
         view.side_tol = p.side_tol;
+        view.e_s      = p.fb_e_s;
+        view.e_t      = p.fb_e_t;
+        view.e_s_over_e_t = p.fb_e_t > 0.F ? p.fb_e_s / p.fb_e_t : 0.F;
     }
     return view;
+}
+
+// chi(origin) = 1 for certain?  (front / back split: ok_grid.h has the argument, ok_raycast.h's okOriginChiScalar the test as one
+// thread makes it.)  Here the pairs of the origin cell's front chunk are dealt to the G lanes of the agent's group, lane r taking
+// pairs r, r + G, ...; the classes are the scalar test's, their parity and "any pair that cannot be told" come together by two
+// ballots.  Every lane of the group returns the same answer.
+// *clear: a radius around the origin inside which the answer cannot change -- chi is a function of the position alone and flips
+// only across F, so it holds wherever no F segment can be reached: a lower bound of the distance to the F segments registered
+// in the cell (each by its bounding box) and to the cell's own border (every other F segment lies beyond that).  The step loop
+// repeats the test only when the origin has left that circle (an agent moves 1.6 px per step at most).
+__device__ __forceinline__ bool okOriginChiGroup(const OkPolyView &front, const float ox, const float oy, const int r, const int G, const float t12,
+                                                 const float t34, float *clear)
+{
+    const OkGridGeom &g      = front.g;
+    const bool        inside = ox >= g.x0 && ox <= g.x1 && oy >= g.y0 && oy <= g.y1; // (false for NaN poses)
+    int               ix     = (int)__builtin_floorf((ox - g.x0) * g.inv_cell);
+    int               iy     = (int)__builtin_floorf((oy - g.y0) * g.inv_cell);
+    ix                       = ix < 0 ? 0 : (ix >= g.nx ? g.nx - 1 : ix);
+    iy                       = iy < 0 ? 0 : (iy >= g.ny ? g.ny - 1 : iy);
+    const OkCellHdr hc       = front.hdr[inside ? iy * g.nx + ix : 0];
+    const uint32_t  flags    = hc.w0 >> OKFB_HDR_SHIFT_RC;
+    const bool      usable   = inside && (flags & OKFB_RC_CERT) != 0U;
+    float           rx, ry;
+    okCellRefPoint(g, ix, iy, (flags >> 2) & 3U, &rx, &ry);
+    const uint32_t k0 = hc.w0 & OKPOLY_IDX_MASK;
+    const uint32_t n  = usable ? ((hc.w0 >> OKPOLY_IDX_BITS) & OKPOLY_N_MASK) : 0U;
+    const uint32_t n8 = (n + 7U) & ~7U;
+    bool           amb = false, odd = false;
+    // distance to the cell's border (the cell's corners in the walk's own arithmetic)
+    const float cx0 = g.x0 + static_cast<float>(ix) * g.cell, cy0 = g.y0 + static_cast<float>(iy) * g.cell;
+    float       near = __builtin_fminf(__builtin_fminf(ox - cx0, (cx0 + g.cell) - ox), __builtin_fminf(oy - cy0, (cy0 + g.cell) - oy));
+    for (uint32_t j = static_cast<uint32_t>(r); j + 1U < n; j += static_cast<uint32_t>(G))
+    {
+        if ((hc.brk >> (n8 - 2U - j)) & 1U) // no segment joins slots j and j + 1
+            continue;
+        const OkPoint pa = front.slots[k0 + j], pb = front.slots[k0 + j + 1U];
+        const int     cls = okChiPairClass(pa, pb, rx, ry, ox, oy, t12, t34);
+        amb               = amb || cls == 2;
+        odd               = odd != (cls == 1);
+        // Chebyshev distance to the segment's bounding box: never more than the distance to the segment
+        const float bx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(pa.x, pb.x) - ox, ox - __builtin_fmaxf(pa.x, pb.x)), 0.F);
+        const float by = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(pa.y, pb.y) - oy, oy - __builtin_fmaxf(pa.y, pb.y)), 0.F);
+        near           = __builtin_fminf(near, __builtin_fmaxf(bx, by));
+    }
+    near   = okGroupMin(near, G);
+    *clear = usable ? 0.99F * near - 1.0e-3F : 0.F; // (rounding of the distances and of the later comparison: far below the slack)
+    unsigned long long b_amb = __ballot(amb), b_odd = __ballot(odd);
+    if (G < 64)
+    {
+        const int                base = static_cast<int>(__lane_id()) & ~(G - 1);
+        const unsigned long long mask = ((1ULL << G) - 1ULL) << base;
+        b_amb &= mask;
+        b_odd &= mask;
+    }
+    const uint32_t chi = ((flags & OKFB_RC_CHI) ? 1U : 0U) ^ (static_cast<uint32_t>(__popcll(b_odd)) & 1U);
+    return usable && b_amb == 0ULL && chi == 1U;
 }
 
 // ---- RLRacers/Q_Learning pieces shared by the step kernels ------------------------------------------------------------
@@ -1216,6 +1281,19 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
             s_ctrl[i] = src[i];
     }
     const OkPolyView view = okSetupView<kGridLds>(p, ok_lds); // ends with a barrier
+    // front / back split (ok_grid.h): `view` is the front image then; the back image behind it is walked only by rays whose
+    // origin is not certified to lie where back segments cannot come first, or whose front walk may have missed a crossing.
+    // The packed / resident / direct forms keep the combined image (the host never sets fb for them).
+    constexpr bool kFb = !kPacked && !kResident && !kDirect;
+    const bool     fb  = kFb && p.fb != 0U;
+    constexpr bool kAmbW = kFb; // the front image's walks report candidates a crossing may hide behind (ok_first_hit_update)
+    OkPolyView     view_back = view;
+    if (fb)
+    {
+        view_back.slots    = reinterpret_cast<const OkPoint *>(ok_lds + p.fb_back_off);
+        view_back.hdr      = reinterpret_cast<const OkCellHdr *>(ok_lds + p.fb_back_off_hdr);
+        view_back.side_tol = p.fb_back_side_tol;
+    }
 #if OKENV_PRIO == 2
     // which of the CU's four SIMDs this wave runs on (HW_REG_HW_ID bits 5:4): waves of one SIMD compete for its issue slots
     const uint32_t my_simd = (__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4)) & 3U;
@@ -1346,6 +1424,9 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
         OkMlpColumn<32> mlp_col;
         if (wide_mlp)
             mlp_col = okMlpFetchColumn<32>(p, a, r);
+        // front / back split: the last origin test of this lane's agent (position, cleared radius, answer)
+        float cert_ox = 0.F, cert_oy = 0.F, cert_clear = 0.F;
+        bool  cert_state = false;
         bool      settled = !agent_ok || (episode && p.settled[a] != 0); // episodes: nothing left to do for this lane's agent
         uint32_t  live_n  = 0U;                                          // steps this agent entered alive
         for (int s = 0; s < n_steps; ++s)
@@ -1435,6 +1516,21 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
             const float ox     = ag.pos_x + p.sensor_offset * cr;
             const float oy     = ag.pos_y + p.sensor_offset * sr;
             const bool  casts  = ray_ok && !ag.crashed;
+            // front / back split: is the agent's ray origin certainly on the side of the inner boundaries where no back segment can
+            // be a ray's first hit?  (one answer per agent; its rays' front walks report ambiguous rejections in amb_ray)
+            bool cert = false, amb_ray = false;
+            if (fb)
+            { // (the answer of the last test stands while the origin stays inside the circle that test cleared; a re-placed agent
+              // is far outside it, a NaN pose fails the comparison)
+                const float moved = __builtin_fabsf(ox - cert_ox) + __builtin_fabsf(oy - cert_oy);
+                if (!(moved < cert_clear))
+                {
+                    cert_state = okOriginChiGroup(view, ox, oy, r, G, p.fb_t12, p.fb_t34, &cert_clear);
+                    cert_ox    = ox;
+                    cert_oy    = oy;
+                }
+                cert = cert_state;
+            }
 
             OK_STAMP(1);
             float min_t = OK_SENSOR_RANGE; // the ray's first-hit parameter
@@ -1468,10 +1564,11 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
             else if (casts && phase1_range > 0.F)
             {
                 const OkIntervalResult r1 =
-                    ok_cast_poly_interval<false>(view, ox, oy, rdx, rdy, 0.F, phase1_range, nullptr, nullptr, nullptr OK_WPROF(0));
+                    ok_cast_poly_interval<false, kAmbW>(view, ox, oy, rdx, rdy, 0.F, phase1_range, nullptr, nullptr, nullptr OK_WPROF(0));
                 min_t      = r1.min_t;
                 unfinished = !r1.conclusive;
                 t_reached  = r1.t_reached;
+                amb_ray    = kFb && r1.amb;
             }
             else
                 unfinished = casts; // no phase 1 (spare lanes, but a policy that wants ray r on lane r): phase 2 cuts the whole ray
@@ -1510,6 +1607,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                 const float tdy   = __shfl(rdy, owner, 64);
                 const float t0    = __shfl(t_reached, owner, 64);
                 float       found = OK_SENSOR_RANGE;
+                bool        amb2  = false;
                 if (has)
                 {
                     // neighbouring lanes evaluate the shared bound with the same expression, the last interval is open-ended:
@@ -1521,8 +1619,9 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                     // this one -- so the walk steps over its start cell unless the ray enters it inside [ta, tb): each cell of a pending
                     // ray is looked at once, not twice (3.3 -> 2.x cell iterations per wave-step in lock step).
                     const OkIntervalResult r2 =
-                        ok_cast_poly_interval<false>(view, tox, toy, tdx, tdy, ta, tb, nullptr, nullptr, nullptr OK_WPROF(5), j > 0 || t0 > 0.F);
+                        ok_cast_poly_interval<false, kAmbW>(view, tox, toy, tdx, tdy, ta, tb, nullptr, nullptr, nullptr OK_WPROF(5), j > 0 || t0 > 0.F);
                     found                     = r2.min_t;
+                    amb2                      = kFb && r2.amb;
                 }
                 // min over the m lanes of a ray (consecutive lanes), then back to the owner
                 const int first = unfinished ? rank * m : 0;
@@ -1538,9 +1637,22 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                 mine = __shfl(found, first, 64);
                 if (unfinished && mine < min_t)
                     min_t = mine;
+                if (kFb)
+                { // an ambiguous rejection in any of the ray's m intervals (lanes first .. first + m - 1) is the ray's
+                    const unsigned long long b_amb = __ballot(amb2);
+                    if (unfinished && ((b_amb >> first) & ((1ULL << m) - 1ULL)) != 0ULL)
+                        amb_ray = true;
+                }
 #if OKENV_PRIO == 1
                 __builtin_amdgcn_s_setprio(0);
 #endif
+            }
+            if (kFb && fb)
+            { // the back image, for the rays that need it: from the origin to the front image's first hit (min over front and back =
+              // min over all segments, whatever the origin)
+                const bool need_back = casts && (!cert || amb_ray);
+                if (__ballot(need_back) != 0ULL && need_back)
+                    min_t = ok_cast_poly_interval<false>(view_back, ox, oy, rdx, rdy, 0.F, OKRC_INF, nullptr, nullptr, nullptr, nullptr, false, min_t).min_t;
             }
             OK_STAMP(5);
             if (wide_mlp)

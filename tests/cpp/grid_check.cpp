@@ -128,4 +128,100 @@ extern "C"
         }
         return 0;
     }
+
+    // The front / back split (ok_grid.h: okClassifyFrontBack) as the cooperative kernel uses it, ray by ray on the host:
+    //   chi(origin) certain (okOriginChiScalar)?  front walk -- whole ray (parts = 1) or the kernel's decomposition ([0, 48], then
+    //   `parts` intervals of what is left, start cells owned by one walk) -- reporting ambiguous rejections; rays whose origin is not
+    //   certified or whose front walk was ambiguous walk the back image too, starting from the front's first hit.
+    // out_flags: bit 0 origin certified, bit 1 front walk ambiguous, bit 2 back image walked.
+    // info: [0] split exists, [1] F segments, [2] back segments, [3] other front segments, [4] certifiable cells, [5] cells holding
+    //       front segments, [6] front image bytes, [7] back image bytes, [8] combined image bytes, [9] cells
+    // force_back != 0: every ray walks the back image (what an uncertified agent costs; also "front + back = all segments")
+    __attribute__((visibility("default"))) int gridcheck_cast_fb(const float *segs_xyxy, int S, float cell, const float *ox, const float *oy,
+                                                                 const float *angle_rad, int n, float *out_t, uint32_t *out_flags, int32_t *info,
+                                                                 int parts, int force_back, uint32_t *out_points)
+    {
+        const OkSeg *segs = reinterpret_cast<const OkSeg *>(segs_xyxy);
+        bool         fits = false;
+        OkPolyImage  combined;
+        OkGridHost   gh = okBuildGridAuto(segs, static_cast<size_t>(S), cell, 160U * 1024U, &fits, &combined);
+        if (!fits)
+            return -1;
+        OkFrontBack       fb   = okClassifyFrontBack(segs, static_cast<size_t>(S), gh, combined.max_seg_len);
+        OkFrontBackImages imgs = okBuildFrontBackImages(segs, static_cast<size_t>(S), gh, fb);
+        if (info)
+        {
+            info[0] = imgs.ok ? 1 : 0;
+            info[1] = static_cast<int32_t>(fb.n_f);
+            info[2] = static_cast<int32_t>(fb.n_back);
+            info[3] = static_cast<int32_t>(fb.n_front_other);
+            info[4] = static_cast<int32_t>(fb.n_cells_cert);
+            info[5] = static_cast<int32_t>(fb.n_cells_with_front);
+            info[6] = static_cast<int32_t>(imgs.front.bytes.size());
+            info[7] = static_cast<int32_t>(imgs.back.bytes.size());
+            info[8] = static_cast<int32_t>(combined.bytes.size());
+            info[9] = static_cast<int32_t>(gh.numCells());
+        }
+        if (!imgs.ok)
+            return 1;
+        OkPolyView vf{}, vb{};
+        vf.g        = gh.g;
+        vf.slots    = reinterpret_cast<const OkPoint *>(imgs.front.bytes.data());
+        vf.hdr      = reinterpret_cast<const OkCellHdr *>(imgs.front.bytes.data() + imgs.front.off_hdr);
+        vf.side_tol = imgs.front.side_tol;
+        vf.e_s      = fb.e_s;
+        vf.e_t      = fb.e_t;
+        vf.e_s_over_e_t = fb.e_s / fb.e_t;
+        vb          = vf;
+        vb.slots    = reinterpret_cast<const OkPoint *>(imgs.back.bytes.data());
+        vb.hdr      = reinterpret_cast<const OkCellHdr *>(imgs.back.bytes.data() + imgs.back.off_hdr);
+        vb.side_tol = imgs.back.side_tol;
+        for (int i = 0; i < n; ++i)
+        {
+            float s, c;
+            ok_sincosf(angle_rad[i], &s, &c);
+            uint32_t  tests = 0, cells = 0, points = 0;
+            const int cert  = okOriginChiScalar(vf, ox[i], oy[i], fb.t12, fb.t34);
+            float     best  = OK_SENSOR_RANGE;
+            bool      amb   = false;
+            if (parts <= 1)
+            {
+                const OkIntervalResult r = ok_cast_poly_interval<true, true>(vf, ox[i], oy[i], c, s, 0.0F, OKRC_INF, &tests, &cells, &points);
+                best                     = r.min_t;
+                amb                      = r.amb;
+            }
+            else
+            {
+                const OkIntervalResult r1 = ok_cast_poly_interval<true, true>(vf, ox[i], oy[i], c, s, 0.0F, 48.0F, &tests, &cells, &points);
+                best                      = r1.min_t;
+                amb                       = r1.amb;
+                if (!r1.conclusive)
+                {
+                    const float t0 = r1.t_reached, dt = (OK_SENSOR_RANGE - t0) / (float)parts;
+                    for (int j = 0; j < parts; ++j)
+                    {
+                        const float            ta = t0 + (float)j * dt, tb = (j == parts - 1) ? OKRC_INF : t0 + (float)(j + 1) * dt;
+                        const OkIntervalResult r2 =
+                            ok_cast_poly_interval<true, true>(vf, ox[i], oy[i], c, s, ta, tb, &tests, &cells, &points, nullptr, j > 0 || t0 > 0.0F);
+                        best = r2.min_t < best ? r2.min_t : best;
+                        amb  = amb || r2.amb;
+                    }
+                }
+            }
+            uint32_t flags = (cert ? 1U : 0U) | (amb ? 2U : 0U);
+            if (!cert || amb || force_back)
+            {
+                const OkIntervalResult rb =
+                    ok_cast_poly_interval<true, false>(vb, ox[i], oy[i], c, s, 0.0F, OKRC_INF, &tests, &cells, &points, nullptr, false, best);
+                best = rb.min_t;
+                flags |= 4U;
+            }
+            out_t[i] = best;
+            if (out_flags)
+                out_flags[i] = flags;
+            if (out_points)
+                out_points[i] = points;
+        }
+        return 0;
+    }
 }
