@@ -494,6 +494,8 @@ bool directIntervals(const okenv *h)
     return h->phase1_range <= 0.F && h->G >= 2 * h->R;
 }
 
+void useFrontBack(const okenv *h, OkStepParams &p);
+
 // Starts the resident kernel on a stream of its own; `p` carries the exchange pointers of okenv_step_packed.
 int startResident(okenv *h, OkStepParams p, volatile uint32_t *slots)
 {
@@ -504,12 +506,20 @@ int startResident(okenv *h, OkStepParams p, volatile uint32_t *slots)
         slots[i] = 0U;
     std::atomic_thread_fence(std::memory_order_seq_cst);
     p.done_seq = okNextPackedSeq(h->packed_seq); // the first number the kernel waits for
+    size_t   lds = coopLdsBytes(h);
+    uint32_t off = static_cast<uint32_t>(h->image_bytes);
+    if (h->fb_ok && h->fb_bytes + kCoopLdsExtra <= kLdsBudget)
+    { // the front / back split (staged once for the kernel's whole residency)
+        useFrontBack(h, p);
+        off = static_cast<uint32_t>(h->fb_bytes);
+        lds = h->fb_bytes + kCoopLdsExtra;
+    }
     if (directIntervals(h))
-        hipLaunchKernelGGL((okStepCoopKernel<kPolicyNone, true, true, true>), dim3(h->grid_blocks), dim3(h->block_threads), coopLdsBytes(h),
-                           h->resident_stream, p, static_cast<uint32_t>(h->image_bytes), h->phase1_range);
+        hipLaunchKernelGGL((okStepCoopKernel<kPolicyNone, true, true, true>), dim3(h->grid_blocks), dim3(h->block_threads), lds, h->resident_stream, p, off,
+                           h->phase1_range);
     else
-        hipLaunchKernelGGL((okStepCoopKernel<kPolicyNone, true, true>), dim3(h->grid_blocks), dim3(h->block_threads), coopLdsBytes(h),
-                           h->resident_stream, p, static_cast<uint32_t>(h->image_bytes), h->phase1_range);
+        hipLaunchKernelGGL((okStepCoopKernel<kPolicyNone, true, true>), dim3(h->grid_blocks), dim3(h->block_threads), lds, h->resident_stream, p, off,
+                           h->phase1_range);
     OK_HIP(h, hipGetLastError());
     h->resident = true;
     return OKENV_OK;
@@ -618,6 +628,23 @@ int waitPackedDone(okenv *h, const volatile uint32_t *word, const uint32_t seq)
 
 long tailLimit(const okenv *h, bool q_launch);
 
+// Points a launch at the [front | back] images instead of the combined one (ok_grid.h: okClassifyFrontBack).
+void useFrontBack(const okenv *h, OkStepParams &p)
+{
+    p.image            = h->d_image_fb;
+    p.image_bytes      = static_cast<uint32_t>(h->fb_bytes);
+    p.off_hdr          = static_cast<uint32_t>(h->fbi.front.off_hdr);
+    p.side_tol         = h->fbi.front.side_tol;
+    p.fb               = 1U;
+    p.fb_back_off      = static_cast<uint32_t>(h->fb_back_off);
+    p.fb_back_off_hdr  = static_cast<uint32_t>(h->fb_back_off + h->fbi.back.off_hdr);
+    p.fb_back_side_tol = h->fbi.back.side_tol;
+    p.fb_e_s           = h->fbc.e_s;
+    p.fb_e_t           = h->fbc.e_t;
+    p.fb_t12           = h->fbc.t12;
+    p.fb_t34           = h->fbc.t34;
+}
+
 int launchStep(okenv *h, OkStepParams p) // (by value: the diagnostic build adds its stamp buffer)
 {
     OK_HIP(h, hipSetDevice(h->device));
@@ -674,12 +701,21 @@ int launchStep(okenv *h, OkStepParams p) // (by value: the diagnostic build adds
         // (Q-learning: one more wave, without rays -- it looks up the nearest centre-line index while the others walk -- and the
         // agent's table in LDS)
         const unsigned lanes = static_cast<unsigned>(((h->R * kTailSplit + 63) / 64) * 64) + (q_launch ? 64U : 0U);
-        const size_t   lds   = h->image_bytes + 16U + sizeof(float) * kTailLdsFloats + (q_launch ? qLdsBytes(h) + sizeof(float) * kTailQFloats : 0U);
+        size_t         lds   = h->image_bytes + 16U + sizeof(float) * kTailLdsFloats + (q_launch ? qLdsBytes(h) + sizeof(float) * kTailQFloats : 0U);
         if (p.n_active <= tailLimit(h, q_launch))
         {
             p.G = h->G; // (unused by the tail kernel; undo the widening above)
-            const dim3     tgrid(static_cast<unsigned>(p.n_active)), tblock(lanes);
-            const uint32_t off = static_cast<uint32_t>(h->image_bytes);
+            const dim3 tgrid(static_cast<unsigned>(p.n_active)), tblock(lanes);
+            uint32_t   off = static_cast<uint32_t>(h->image_bytes);
+            // the front / back split while the list fits one round of workgroups with the larger image (fewer of them share a CU);
+            // longer lists keep the combined image and their two workgroups per CU
+            const size_t lds_fb = lds - h->image_bytes + h->fb_bytes;
+            if (h->fb_ok && lds_fb <= kLdsBudget && static_cast<long>(p.n_active) <= static_cast<long>(kLdsBudget / lds_fb) * h->cus)
+            {
+                useFrontBack(h, p);
+                off = static_cast<uint32_t>(h->fb_bytes);
+                lds = lds_fb;
+            }
 #if defined(OKENV_STAMPS)
             { // [0] policy, [1] pre-step, [3] interval walk + min, [5] epilogue, [6] barrier, [7] crash test + Q-learning; [2] / [4] start / end
                 const size_t waves = static_cast<size_t>(p.n_active) * (lanes / 64U);
@@ -723,26 +759,13 @@ int launchStep(okenv *h, OkStepParams p) // (by value: the diagnostic build adds
         {
             size_t   lds = coopLdsBytes(h);
             uint32_t off = static_cast<uint32_t>(h->image_bytes);
-            // the front / back split, for the instantiations that have it (not the packed exchange, not the direct dealing of small
-            // populations: those keep the combined image) and when everything else the launch stages still fits behind it
+            // the front / back split, when everything else the launch stages still fits behind it
             const bool has_extra = p.action_source == kActionsQLearning || p.action_source == kActionsController;
-            if (h->fb_ok && p.rec_in == nullptr && !(policy == kPolicyNone && !has_extra && directIntervals(h)) &&
-                h->fb_bytes + kCoopLdsExtra + (has_extra ? qLdsBytes(h) : 0U) <= kLdsBudget)
+            if (h->fb_ok && h->fb_bytes + kCoopLdsExtra + (has_extra ? qLdsBytes(h) : 0U) <= kLdsBudget)
             {
-                p.image            = h->d_image_fb;
-                p.image_bytes      = static_cast<uint32_t>(h->fb_bytes);
-                p.off_hdr          = static_cast<uint32_t>(h->fbi.front.off_hdr);
-                p.side_tol         = h->fbi.front.side_tol;
-                p.fb               = 1U;
-                p.fb_back_off      = static_cast<uint32_t>(h->fb_back_off);
-                p.fb_back_off_hdr  = static_cast<uint32_t>(h->fb_back_off + h->fbi.back.off_hdr);
-                p.fb_back_side_tol = h->fbi.back.side_tol;
-                p.fb_e_s           = h->fbc.e_s;
-                p.fb_e_t           = h->fbc.e_t;
-                p.fb_t12           = h->fbc.t12;
-                p.fb_t34           = h->fbc.t34;
-                off                = static_cast<uint32_t>(h->fb_bytes);
-                lds                = h->fb_bytes + kCoopLdsExtra;
+                useFrontBack(h, p);
+                off = static_cast<uint32_t>(h->fb_bytes);
+                lds = h->fb_bytes + kCoopLdsExtra;
             }
             if (p.action_source == kActionsQLearning)
                 hipLaunchKernelGGL(okStepCoopKernel<kPolicyQ>, grid, block, lds + qLdsBytes(h), h->stream, p, off, phase1);
@@ -947,7 +970,7 @@ extern "C"
                 }
             }
             OK_HIP(nullptr, hipStreamSynchronize(h->stream));
-            const int lds_plain = static_cast<int>(h->image_bytes), lds_coop = static_cast<int>(coopLdsBytes(h));
+            const int lds_plain = static_cast<int>(h->image_bytes);
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepKernel<kGridLds, kPolicyNone>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_plain));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepKernel<kGridLds, kPolicyMlp>),
@@ -955,19 +978,19 @@ extern "C"
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, true, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, false, false, false, 64, true>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, false, false, false, 64>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, false, false, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, true, false, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyNone, true, true, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_coop));
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyMlp>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBudget)));
             OK_HIP(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(&okStepCoopKernel<kPolicyQ>),

@@ -1283,9 +1283,9 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
     const OkPolyView view = okSetupView<kGridLds>(p, ok_lds); // ends with a barrier
     // front / back split (ok_grid.h): `view` is the front image then; the back image behind it is walked only by rays whose
     // origin is not certified to lie where back segments cannot come first, or whose front walk may have missed a crossing.
-    // The packed / resident / direct forms keep the combined image (the host never sets fb for them).
-    constexpr bool kFb = !kPacked && !kResident && !kDirect;
-    const bool     fb  = kFb && p.fb != 0U;
+    // (the host decides per launch: p.fb)
+    constexpr bool kFb = true;
+    const bool     fb  = p.fb != 0U;
     constexpr bool kAmbW = kFb; // the front image's walks report candidates a crossing may hide behind (ok_first_hit_update)
     OkPolyView     view_back = view;
     if (fb)
@@ -1539,27 +1539,47 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
             float t_reached  = 0.F;
             if (direct)
             { // the lane's own interval of its ray; the intervals tile [0, inf) whatever dt rounds to (last one open-ended)
-                float found = OK_SENSOR_RANGE;
+                float       found = OK_SENSOR_RANGE;
+                bool        amb1  = false;
+                const float dt    = OK_SENSOR_RANGE * okRcpApprox(static_cast<float>(dm));
+                const float ta    = static_cast<float>(part) * dt;
+                const float tb    = (part + 1 == dm) ? OKRC_INF : static_cast<float>(part + 1) * dt;
                 if (casts)
                 {
-                    const float dt = OK_SENSOR_RANGE * okRcpApprox(static_cast<float>(dm));
-                    const float ta = static_cast<float>(part) * dt;
-                    const float tb = (part + 1 == dm) ? OKRC_INF : static_cast<float>(part + 1) * dt;
                     // (lanes after the first leave the cell they start in to their neighbour when the ray entered it before ta)
-                    found          = ok_cast_poly_interval<false>(view, ox, oy, rdx, rdy, ta, tb, nullptr, nullptr, nullptr OK_WPROF(5), part > 0).min_t;
+                    const OkIntervalResult rd =
+                        ok_cast_poly_interval<false, kAmbW>(view, ox, oy, rdx, rdy, ta, tb, nullptr, nullptr, nullptr OK_WPROF(5), part > 0);
+                    found = rd.min_t;
+                    amb1  = rd.amb;
                 }
-                if ((dm & (dm - 1)) == 0)
-                    found = okGroupMin(found, dm); // aligned groups of a power of two: DPP
-                else
-                {
+                // min over the dm lanes of a ray (valid on the ray's first lane at least, which is the one that uses it)
+                auto ray_min = [&](float v) {
+                    if ((dm & (dm - 1)) == 0)
+                        return okGroupMin(v, dm); // aligned groups of a power of two: DPP
                     for (int off = 1; off < dm; off <<= 1)
                     {
-                        const float other = __shfl_down(found, off, 64);
-                        if (part + off < dm && other < found)
-                            found = other;
+                        const float other = __shfl_down(v, off, 64);
+                        if (part + off < dm && other < v)
+                            v = other;
+                    }
+                    return v;
+                };
+                found = ray_min(found);
+                if (fb)
+                { // the back image for the rays that need it, cut like the front walk, from the front's first hit down
+                    const int                first     = static_cast<int>(__lane_id()) - part;
+                    const unsigned long long b_amb     = __ballot(amb1);
+                    const bool               need_back = casts && (!cert || ((b_amb >> first) & ((1ULL << dm) - 1ULL)) != 0ULL);
+                    if (__ballot(need_back) != 0ULL)
+                    {
+                        const float front_t = __shfl(found, first, 64);
+                        float       back_t  = front_t;
+                        if (need_back && ta <= front_t)
+                            back_t = ok_cast_poly_interval<false>(view_back, ox, oy, rdx, rdy, ta, tb, nullptr, nullptr, nullptr, nullptr, part > 0, front_t).min_t;
+                        found = ray_min(back_t);
                     }
                 }
-                min_t = found; // (valid on the ray's first lane, which is the one that uses it)
+                min_t = found;
             }
             else if (casts && phase1_range > 0.F)
             {
@@ -1647,7 +1667,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                 __builtin_amdgcn_s_setprio(0);
 #endif
             }
-            if (kFb && fb)
+            if (!direct && fb)
             { // the back image, for the rays that need it: from the origin to the front image's first hit (min over front and back =
               // min over all segments, whatever the origin)
                 const bool need_back = casts && (!cert || amb_ray);
@@ -1909,6 +1929,18 @@ __global__ void __launch_bounds__(kPolicy == kPolicyQ ? 576 : 512) okStepTailKer
         s_xs[ray]      = d0 / 200.0F;
     }
     const OkPolyView view = okSetupView<kGridLds>(p, ok_lds); // ends with a barrier
+    // front / back split (ok_grid.h), as in the cooperative kernel: `view` is the front image then, the back image is walked by the
+    // rays that need it; every wave makes the agent's origin test for itself (same inputs, same answer)
+    const bool fb        = p.fb != 0U;
+    OkPolyView view_back = view;
+    if (fb)
+    {
+        view_back.slots    = reinterpret_cast<const OkPoint *>(ok_lds + p.fb_back_off);
+        view_back.hdr      = reinterpret_cast<const OkCellHdr *>(ok_lds + p.fb_back_off_hdr);
+        view_back.side_tol = p.fb_back_side_tol;
+    }
+    float cert_ox = 0.F, cert_oy = 0.F, cert_clear = 0.F;
+    bool  cert_state = false;
 
     OkQCarry qs{};
     float    qc0 = 0.F, qc1 = 0.F, qc2 = 0.F;
@@ -2022,16 +2054,44 @@ __global__ void __launch_bounds__(kPolicy == kPolicyQ ? 576 : 512) okStepTailKer
         const float oy    = ag.pos_y + p.sensor_offset * sr;
         const bool  casts = ray_ok && !ag.crashed;
         OK_TSTAMP(1);
+        bool cert = false;
+        if (fb)
+        { // (cooperative kernel: the answer of the last origin test stands while the origin stays inside the circle it cleared)
+            const float moved = __builtin_fabsf(ox - cert_ox) + __builtin_fabsf(oy - cert_oy);
+            if (!(moved < cert_clear))
+            {
+                cert_state = okOriginChiGroup(view, ox, oy, lane, 64, p.fb_t12, p.fb_t34, &cert_clear);
+                cert_ox    = ox;
+                cert_oy    = oy;
+            }
+            cert = cert_state;
+        }
         // the lane's interval of its ray; the intervals tile [0, inf) whatever dt rounds to (the last one is open-ended)
-        float found = OK_SENSOR_RANGE;
+        float       found = OK_SENSOR_RANGE;
+        bool        amb   = false;
+        const float dt    = OK_SENSOR_RANGE * okRcpApprox(static_cast<float>(kTailSplit));
+        const float ta    = static_cast<float>(part) * dt;
+        const float tb    = (part + 1 == kTailSplit) ? OKRC_INF : static_cast<float>(part + 1) * dt;
         if (casts)
         {
-            const float dt = OK_SENSOR_RANGE * okRcpApprox(static_cast<float>(kTailSplit));
-            const float ta = static_cast<float>(part) * dt;
-            const float tb = (part + 1 == kTailSplit) ? OKRC_INF : static_cast<float>(part + 1) * dt;
-            found          = ok_cast_poly_interval<false>(view, ox, oy, rdx, rdy, ta, tb, nullptr, nullptr, nullptr, OK_TWALK, part > 0).min_t;
+            const OkIntervalResult rf = ok_cast_poly_interval<false, true>(view, ox, oy, rdx, rdy, ta, tb, nullptr, nullptr, nullptr, OK_TWALK, part > 0);
+            found                     = rf.min_t;
+            amb                       = rf.amb;
         }
         found = okGroupMin(found, kTailSplit);
+        if (fb)
+        { // the back image for the rays that need it, cut like the front walk; an interval beyond the front's first hit has nothing to add
+            const unsigned long long b_amb     = __ballot(amb);
+            const bool               amb_ray   = ((b_amb >> (lane & ~(kTailSplit - 1))) & ((1ULL << kTailSplit) - 1ULL)) != 0ULL;
+            const bool               need_back = casts && (!cert || amb_ray); // (the same in the kTailSplit lanes of a ray)
+            if (__ballot(need_back) != 0ULL)
+            {
+                float fb_found = found;
+                if (need_back && ta <= found)
+                    fb_found = ok_cast_poly_interval<false>(view_back, ox, oy, rdx, rdy, ta, tb, nullptr, nullptr, nullptr, nullptr, part > 0, found).min_t;
+                found = okGroupMin(fb_found, kTailSplit);
+            }
+        }
         if (kPolicy == kPolicyQ && wave == n_waves - 1)
         { // the wave without rays: RaceTrack::findNearestTrackIndexBruteForce of the new position, while the others walk
             const int nearest_here = okNearestBucketed(p, lds_cx, lds_cy, lds_cstart, lds_cidx, ag.pos_x, ag.pos_y, lane, 64);
