@@ -654,9 +654,14 @@ def main():
     crashed_frac = float(state["crashed"].mean())
     work = None
     try:  # what the broad phase leaves of the reference's R x S tests per agent-step, at the population's poses right now
-        ws = env.work_stats()
+        split = info.get("front_back_bytes", 0) > 0
+        ws = env.work_stats_split() if split else env.work_stats()
         if ws["rays"] > 0:
             work = {k: ws[k] / float(ws["rays"]) for k in ("tests", "cells", "points")}
+            if split:
+                work.update({k: ws[k] / float(ws["rays"]) for k in ("certified", "ambiguous", "back_walked")})
+                wc = env.work_stats()
+                work["combined_image"] = {k: wc[k] / float(wc["rays"]) for k in ("tests", "cells", "points")}
     except Exception as e:  # noqa: BLE001
         log("work stats unavailable: %s" % e)
     callers = None
@@ -757,7 +762,7 @@ def main():
                        "agents_per_gpu": N, "rays": R, "track": args.track, "segments": track.S,
                        "global_agents": total_agents, "agent_base_per_rank": [r * N for r in range(world)],
                        "steps_per_launch": spl, "parallelism": "dp%d (agent shards, no collective)" % world,
-                       "grid_cell": info["grid_cell"], "lds_bytes": info["lds_bytes"]},
+                       "grid_cell": info["grid_cell"], "lds_bytes": info["front_back_bytes"] or info["lds_bytes"]},
             "rays_per_sec": value * R,
             # what the reference's sweep would have to evaluate for the same result: every ray against all S segments
             "brute_force_equivalent_ray_segment_tests_per_sec": value * R * track.S,
@@ -769,6 +774,13 @@ def main():
             "broad_phase": None if work is None else {
                 "s_tested_per_ray": work["tests"], "cells_per_ray": work["cells"], "points_per_ray": work["points"],
                 "segments": track.S, "tested_fraction_of_sweep": work["tests"] / track.S,
+                # front / back split of the segment set: share of the rays whose origin is certified to lie between
+                # the inner boundaries, whose front walk was ambiguous, that walked the back image too; and the same poses' figures on
+                # the combined image (what every ray met before the split)
+                "front_back": None if "certified" not in work else {
+                    "rays_of_certified_origins": work["certified"], "ambiguous_front_walks": work["ambiguous"],
+                    "rays_walking_the_back_image": work["back_walked"], "lds_bytes_front_and_back": info["front_back_bytes"],
+                    "back_segments": info["back_segments"], "combined_image_per_ray": work["combined_image"]},
                 "valu_fraction": value / world * R * work["tests"] * 15.0 / 157.3e12},
             "configs": secondary,
             "value_one_launch_per_step": (N * one_steps / one_elapsed) if one_steps else None,

@@ -419,6 +419,12 @@ OKENV_API int okenv_track_segments(okenv_track_t t, float *out_xyxy);
  * Environment/CollisionChecker.cu:49-67, makes num_segments per ray), out[2] = grid cells entered, out[3] = boundary points
  * evaluated by the skip rule.  LDS form of the grid only. */
 OKENV_API int okenv_work_stats(okenv_t h, uint64_t out[4]);
+/* The same walk as the step kernels make it with the front / back split of the segment set (okenv_info.front_back_bytes > 0;
+ * openkitchen_amd/csrc/ok_grid.h: the outer boundary polylines sit in an image of their own and are walked only by rays whose
+ * origin is not certified to lie between the inner boundaries, or whose front walk may have missed a crossing): out[0..3] as
+ * above, front and back walks together; out[4] rays of a certified origin, out[5] rays whose front walk was ambiguous, out[6] rays
+ * that walked the back image too; out[7] unused.  OKENV_ERR_STATE when the segment set has no split. */
+OKENV_API int okenv_work_stats_split(okenv_t h, uint64_t out[8]);
 
 /* ---- device self-checks used by the parity tests --------------------------------------------------- */
 

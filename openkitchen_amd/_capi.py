@@ -47,7 +47,7 @@ SYMBOLS = [
     "okenv_tracker_update", "okenv_step_packed",
     "okenv_controller_create", "okenv_controller_num_params", "okenv_controller_set_params", "okenv_controller_act", "okenv_rollout_controller",
     "okenv_episode_begin", "okenv_episode_compact", "okenv_episode_end", "okenv_episode_tail_limit", "okenv_work_stats",
-    "okenv_ga_scores_device", "okenv_get_stream", "okenv_off_grid_count",
+    "okenv_ga_scores_device", "okenv_get_stream", "okenv_off_grid_count", "okenv_work_stats_split",
 ]
 
 
@@ -162,6 +162,7 @@ def load(build_if_missing=True):
     L.okenv_tracker_update.argtypes = [vp]
     L.okenv_field_device_ptr.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.okenv_work_stats.argtypes = [vp, vp]
+    L.okenv_work_stats_split.argtypes = [vp, vp]
     L.okenv_episode_begin.argtypes = [vp]
     L.okenv_episode_compact.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.okenv_episode_end.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_uint64)]

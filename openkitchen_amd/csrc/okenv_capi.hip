@@ -2659,32 +2659,47 @@ extern "C"
         return OKENV_OK;
     }
 
+    static int workStats(okenv_t h, uint64_t *out, const int n_out, const bool split, const char *who)
+    {
+        if (!h || !out)
+            return fail(h, OKENV_ERR_INVALID, std::string(who) + ": NULL argument");
+        if (h->grid_mode != kGridLds)
+            return fail(h, OKENV_ERR_STATE, std::string(who) + ": needs the LDS form of the grid");
+        if (split && !h->fb_ok)
+            return fail(h, OKENV_ERR_STATE, std::string(who) + ": the segment set has no front / back split (okenv_info.front_back_bytes == 0)");
+        OK_HIP(h, hipSetDevice(h->device));
+        void     *sp  = nullptr;
+        const int src = deviceScratch(h, 8U * sizeof(unsigned long long), &sp);
+        if (src != OKENV_OK)
+            return src;
+        OK_HIP(h, hipMemsetAsync(sp, 0, 8U * sizeof(unsigned long long), h->stream));
+        OkStepParams p = baseParams(h);
+        if (split)
+            useFrontBack(h, p);
+        OK_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&okWorkStatsKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(kLdsBudget)));
+        const long total  = static_cast<long>(h->N) * h->R;
+        const int  blocks = static_cast<int>(std::min<long>(256, (total + 1023) / 1024));
+        hipLaunchKernelGGL(okWorkStatsKernel, dim3(blocks), dim3(1024), p.image_bytes, h->stream, p, static_cast<unsigned long long *>(sp));
+        OK_HIP(h, hipGetLastError());
+        unsigned long long host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        OK_HIP(h, hipMemcpyAsync(host, sp, sizeof(host), hipMemcpyDeviceToHost, h->stream));
+        OK_HIP(h, hipStreamSynchronize(h->stream));
+        for (int i = 0; i < n_out; ++i)
+            out[i] = host[i];
+        return OKENV_OK;
+    }
+
     int okenv_work_stats(okenv_t h, uint64_t out[4])
     {
         OK_QUIESCE(h);
-        if (!h || !out)
-            return fail(h, OKENV_ERR_INVALID, "okenv_work_stats: NULL argument");
-        if (h->grid_mode != kGridLds)
-            return fail(h, OKENV_ERR_STATE, "okenv_work_stats: needs the LDS form of the grid");
-        OK_HIP(h, hipSetDevice(h->device));
-        void     *sp  = nullptr;
-        const int src = deviceScratch(h, 4U * sizeof(unsigned long long), &sp);
-        if (src != OKENV_OK)
-            return src;
-        OK_HIP(h, hipMemsetAsync(sp, 0, 4U * sizeof(unsigned long long), h->stream));
-        OK_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&okWorkStatsKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      static_cast<int>(h->image_bytes)));
-        const long total  = static_cast<long>(h->N) * h->R;
-        const int  blocks = static_cast<int>(std::min<long>(256, (total + 1023) / 1024));
-        hipLaunchKernelGGL(okWorkStatsKernel, dim3(blocks), dim3(1024), h->image_bytes, h->stream, baseParams(h),
-                           static_cast<unsigned long long *>(sp));
-        OK_HIP(h, hipGetLastError());
-        unsigned long long host[4] = {0, 0, 0, 0};
-        OK_HIP(h, hipMemcpyAsync(host, sp, sizeof(host), hipMemcpyDeviceToHost, h->stream));
-        OK_HIP(h, hipStreamSynchronize(h->stream));
-        for (int i = 0; i < 4; ++i)
-            out[i] = host[i];
-        return OKENV_OK;
+        return workStats(h, out, 4, false, "okenv_work_stats");
+    }
+
+    int okenv_work_stats_split(okenv_t h, uint64_t out[8])
+    {
+        OK_QUIESCE(h);
+        return workStats(h, out, 8, true, "okenv_work_stats_split");
     }
 
     int okenv_debug_cast_rays(okenv_t h, const float *ox, const float *oy, const float *angle_rad, int32_t n, float *out_t)

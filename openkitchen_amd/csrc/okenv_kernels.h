@@ -34,6 +34,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/okenv.h"
 #include "ok_raycast.h"
 
@@ -904,8 +906,10 @@ __device__ __forceinline__ bool okOriginChiGroup(const OkPolyView &front, const 
         const float by = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(pa.y, pb.y) - oy, oy - __builtin_fmaxf(pa.y, pb.y)), 0.F);
         near           = __builtin_fminf(near, __builtin_fmaxf(bx, by));
     }
-    near   = okGroupMin(near, G);
-    *clear = usable ? 0.99F * near - 1.0e-3F : 0.F; // (rounding of the distances and of the later comparison: far below the slack)
+    near = okGroupMin(near, G);
+    // (an origin outside the grid box stays uncertified at least until it has covered the distance back to the box)
+    const float outside = __builtin_fmaxf(__builtin_fmaxf(g.x0 - ox, ox - g.x1), __builtin_fmaxf(g.y0 - oy, oy - g.y1));
+    *clear              = usable ? 0.99F * near - 1.0e-3F : (inside ? 0.F : 0.99F * outside - 1.0e-3F); // (slack: rounding here and in the later comparison)
     unsigned long long b_amb = __ballot(amb), b_odd = __ballot(odd);
     if (G < 64)
     {
@@ -1531,7 +1535,6 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                 }
                 cert = cert_state;
             }
-
             OK_STAMP(1);
             float min_t = OK_SENSOR_RANGE; // the ray's first-hit parameter
             // ---- phase 1: own ray over [0, T1] ----------------------------------------------------------
@@ -1547,8 +1550,7 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                 if (casts)
                 {
                     // (lanes after the first leave the cell they start in to their neighbour when the ray entered it before ta)
-                    const OkIntervalResult rd =
-                        ok_cast_poly_interval<false, kAmbW>(view, ox, oy, rdx, rdy, ta, tb, nullptr, nullptr, nullptr OK_WPROF(5), part > 0);
+                    const OkIntervalResult rd = ok_cast_poly_interval<false, kAmbW>(view, ox, oy, rdx, rdy, ta, tb, nullptr, nullptr, nullptr OK_WPROF(5), part > 0);
                     found = rd.min_t;
                     amb1  = rd.amb;
                 }
@@ -1594,9 +1596,16 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                 unfinished = casts; // no phase 1 (spare lanes, but a policy that wants ray r on lane r): phase 2 cuts the whole ray
             OK_STAMP(3);
             // ---- phase 2: the wave's unfinished rays, cut into m intervals each, over the wave's 64 lanes ------
-            const unsigned long long pending = __ballot(unfinished);
-            if (pending != 0ULL)
-            {
+            // One pass of that dealing: the rays of the lanes with `want` set are cut into m = min(8, 64 / their number) intervals of
+            // [t_from, t_limit] (the last one open-ended) over image `vw`, lane L walks interval L % m of pending ray L / m, the m
+            // results are min-combined and pulled back by the owner into min_t.  Used twice: for the rays phase 1 left unfinished
+            // (front image -- the only image without the front / back split), and for the rays that also need the back image (from
+            // the origin to the front image's first hit, which bounds every walk).
+            auto coop_pass = [&](auto amb_tag, const bool want, const OkPolyView &vw, const float t_from, const float t_limit, const bool bounded) {
+                constexpr bool           kA      = decltype(amb_tag)::value;
+                const unsigned long long pending = __ballot(want);
+                if (pending == 0ULL)
+                    return;
                 const int lane = static_cast<int>(__lane_id());
                 const int n    = __popcll(pending);
 #if OKENV_PRIO == 1 // waves with much phase-2 work get issue priority
@@ -1607,12 +1616,12 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
 #endif
                 int       m    = 64 / n;
                 m              = m > kMaxSplit ? kMaxSplit : m;
-                // rank of an unfinished lane among the pending ones; rank -> lane through a forward permute
+                // rank of a pending lane among the pending ones; rank -> lane through a forward permute
                 const int rank  = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pending >> 32),
                                                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pending), 0U)));
                 // (pending lanes go to slots 0..n-1 in lane order, the others fill n..63: a bijection, so no two lanes
                 // write the same slot)
-                const int owner_of_rank = __builtin_amdgcn_ds_permute((unfinished ? rank : n + (lane - rank)) << 2, lane);
+                const int owner_of_rank = __builtin_amdgcn_ds_permute((want ? rank : n + (lane - rank)) << 2, lane);
                 // task of this lane: interval j of pending ray q
                 // (lane + 0.5) / m is never within 1/16 of an integer, so the approximate reciprocal cannot misplace the floor
                 const float inv_m = okRcpApprox(static_cast<float>(m));
@@ -1625,26 +1634,27 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                 const float toy   = kG == 64 ? oy : __shfl(oy, owner, 64);
                 const float tdx   = __shfl(rdx, owner, 64);
                 const float tdy   = __shfl(rdy, owner, 64);
-                const float t0    = __shfl(t_reached, owner, 64);
+                const float t0    = __shfl(t_from, owner, 64);
+                const float tl    = bounded ? __shfl(t_limit, owner, 64) : OK_SENSOR_RANGE;
                 float       found = OK_SENSOR_RANGE;
                 bool        amb2  = false;
                 if (has)
                 {
                     // neighbouring lanes evaluate the shared bound with the same expression, the last interval is open-ended:
                     // the intervals tile [t0, inf) whatever dt rounds to
-                    const float dt = (OK_SENSOR_RANGE - t0) * inv_m;
+                    const float dt = (tl - t0) * inv_m;
                     const float ta = t0 + static_cast<float>(j) * dt;
                     const float tb = (j + 1 == m) ? OKRC_INF : t0 + static_cast<float>(j + 1) * dt;
                     // Every cell the ray entered before ta has been processed -- by phase 1 (t0 > 0) or by the lane of the interval before
                     // this one -- so the walk steps over its start cell unless the ray enters it inside [ta, tb): each cell of a pending
                     // ray is looked at once, not twice (3.3 -> 2.x cell iterations per wave-step in lock step).
                     const OkIntervalResult r2 =
-                        ok_cast_poly_interval<false, kAmbW>(view, tox, toy, tdx, tdy, ta, tb, nullptr, nullptr, nullptr OK_WPROF(5), j > 0 || t0 > 0.F);
-                    found                     = r2.min_t;
-                    amb2                      = kFb && r2.amb;
+                        ok_cast_poly_interval<false, kA>(vw, tox, toy, tdx, tdy, ta, tb, nullptr, nullptr, nullptr OK_WPROF(5), j > 0 || t0 > 0.F, tl);
+                    found = r2.min_t;
+                    amb2  = kA && r2.amb;
                 }
                 // min over the m lanes of a ray (consecutive lanes), then back to the owner
-                const int first = unfinished ? rank * m : 0;
+                const int first = want ? rank * m : 0;
                 float     mine  = OK_SENSOR_RANGE;
                 // (the owner gathering all m results in one round trip measured slower than this shuffle tree plus one pull)
 #pragma unroll
@@ -1655,25 +1665,25 @@ __global__ void __launch_bounds__(1024) okStepCoopKernel(const OkStepParams p_in
                         found = other;
                 }
                 mine = __shfl(found, first, 64);
-                if (unfinished && mine < min_t)
+                if (want && mine < min_t)
                     min_t = mine;
-                if (kFb)
+                if (kA)
                 { // an ambiguous rejection in any of the ray's m intervals (lanes first .. first + m - 1) is the ray's
                     const unsigned long long b_amb = __ballot(amb2);
-                    if (unfinished && ((b_amb >> first) & ((1ULL << m) - 1ULL)) != 0ULL)
+                    if (want && ((b_amb >> first) & ((1ULL << m) - 1ULL)) != 0ULL)
                         amb_ray = true;
                 }
 #if OKENV_PRIO == 1
                 __builtin_amdgcn_s_setprio(0);
 #endif
-            }
+            };
+            if (!direct)
+                coop_pass(std::integral_constant<bool, kAmbW>{}, unfinished, view, t_reached, OK_SENSOR_RANGE, false);
+            // the back image for the rays that need it -- an origin that is not certified, a front walk that may have missed a crossing --
+            // from the origin to the front image's first hit, dealt to the wave's lanes the same way (min over front and back = min over
+            // all segments, whatever the origin)
             if (!direct && fb)
-            { // the back image, for the rays that need it: from the origin to the front image's first hit (min over front and back =
-              // min over all segments, whatever the origin)
-                const bool need_back = casts && (!cert || amb_ray);
-                if (__ballot(need_back) != 0ULL && need_back)
-                    min_t = ok_cast_poly_interval<false>(view_back, ox, oy, rdx, rdy, 0.F, OKRC_INF, nullptr, nullptr, nullptr, nullptr, false, min_t).min_t;
-            }
+                coop_pass(std::false_type{}, casts && (!cert || amb_ray), view_back, 0.F, min_t, true);
             OK_STAMP(5);
             if (wide_mlp)
                 mlp_col = okMlpFetchColumn<32>(p, a, r); // for the next step's policy: in flight during the epilogue
@@ -2945,7 +2955,8 @@ okDebugCastKernel(const OkStepParams p, const float *ox, const float *oy, const 
 // section 8d's valu_fraction): every live agent's rays are walked once, whole (ok_cast_poly_interval<true>), and the exact tests,
 // grid cells and boundary points they meet are summed.  out[0] rays, [1] exact ray-segment tests, [2] cells, [3] points.
 __global__ void __launch_bounds__(1024) okWorkStatsKernel(const OkStepParams p, unsigned long long *out)
-{
+{ // out[0..3]: rays, exact tests, cells, points; with the front / back split (p.fb) also out[4]: rays of a certified origin,
+  // out[5]: rays whose front walk was ambiguous, out[6]: rays that walked the back image
     extern __shared__ __attribute__((aligned(16))) unsigned char ok_lds[];
     okStageImage(p, ok_lds);
     OkPolyView view{};
@@ -2953,7 +2964,17 @@ __global__ void __launch_bounds__(1024) okWorkStatsKernel(const OkStepParams p, 
     view.slots    = reinterpret_cast<const OkPoint *>(ok_lds);
     view.hdr      = reinterpret_cast<const OkCellHdr *>(ok_lds + p.off_hdr);
     view.side_tol = p.side_tol;
-    unsigned long long rays = 0, tests = 0, cells = 0, points = 0;
+    view.e_s      = p.fb_e_s;
+    view.e_t      = p.fb_e_t;
+    view.e_s_over_e_t = p.fb_e_t > 0.F ? p.fb_e_s / p.fb_e_t : 0.F;
+    OkPolyView back = view;
+    if (p.fb != 0U)
+    {
+        back.slots    = reinterpret_cast<const OkPoint *>(ok_lds + p.fb_back_off);
+        back.hdr      = reinterpret_cast<const OkCellHdr *>(ok_lds + p.fb_back_off_hdr);
+        back.side_tol = p.fb_back_side_tol;
+    }
+    unsigned long long rays = 0, tests = 0, cells = 0, points = 0, n_cert = 0, n_amb = 0, n_back = 0;
     const long         total = static_cast<long>(p.N) * p.R;
     for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * blockDim.x)
     {
@@ -2965,7 +2986,20 @@ __global__ void __launch_bounds__(1024) okWorkStatsKernel(const OkStepParams p, 
         ok_sincosf(OK_DEG2RAD * (p.st.rot[a] + p.ray_deg[r]), &rdy, &rdx);
         const float ox = p.st.pos_x[a] + p.sensor_offset * cs, oy = p.st.pos_y[a] + p.sensor_offset * sn;
         uint32_t    t = 0, c = 0, pt = 0;
-        (void)ok_cast_poly_interval<true>(view, ox, oy, rdx, rdy, 0.F, OKRC_INF, &t, &c, &pt);
+        if (p.fb != 0U)
+        {
+            const bool             cert = okOriginChiScalar(view, ox, oy, p.fb_t12, p.fb_t34) != 0;
+            const OkIntervalResult rf   = ok_cast_poly_interval<true, true>(view, ox, oy, rdx, rdy, 0.F, OKRC_INF, &t, &c, &pt);
+            n_cert += cert ? 1U : 0U;
+            n_amb += rf.amb ? 1U : 0U;
+            if (!cert || rf.amb)
+            {
+                (void)ok_cast_poly_interval<true>(back, ox, oy, rdx, rdy, 0.F, OKRC_INF, &t, &c, &pt, nullptr, false, rf.min_t);
+                n_back += 1U;
+            }
+        }
+        else
+            (void)ok_cast_poly_interval<true>(view, ox, oy, rdx, rdy, 0.F, OKRC_INF, &t, &c, &pt);
         rays += 1;
         tests += t;
         cells += c;
@@ -2975,4 +3009,10 @@ __global__ void __launch_bounds__(1024) okWorkStatsKernel(const OkStepParams p, 
     atomicAdd(&out[1], tests);
     atomicAdd(&out[2], cells);
     atomicAdd(&out[3], points);
+    if (p.fb != 0U)
+    {
+        atomicAdd(&out[4], n_cert);
+        atomicAdd(&out[5], n_amb);
+        atomicAdd(&out[6], n_back);
+    }
 }

@@ -393,6 +393,13 @@ class BatchedEnvironment:
         capi.check(self._L.okenv_work_stats(self._h, capi.ptr(out)), self._h)
         return dict(zip(("rays", "tests", "cells", "points"), (int(v) for v in out)))
 
+    def work_stats_split(self):
+        """The same for the walk with the front / back split, as the step kernels make it (okenv_work_stats_split): front and back
+        walks together, plus the rays of a certified origin, the ambiguous front walks and the rays that walked the back image."""
+        out = np.zeros(8, dtype=np.uint64)
+        capi.check(self._L.okenv_work_stats_split(self._h, capi.ptr(out)), self._h)
+        return dict(zip(("rays", "tests", "cells", "points", "certified", "ambiguous", "back_walked"), (int(v) for v in out[:7])))
+
     def set_timing(self, enabled):
         capi.check(self._L.okenv_set_timing(self._h, 1 if enabled else 0), self._h)
 

@@ -210,10 +210,21 @@ extern "C"
             }
             uint32_t flags = (cert ? 1U : 0U) | (amb ? 2U : 0U);
             if (!cert || amb || force_back)
-            {
-                const OkIntervalResult rb =
-                    ok_cast_poly_interval<true, false>(vb, ox[i], oy[i], c, s, 0.0F, OKRC_INF, &tests, &cells, &points, nullptr, false, best);
-                best = rb.min_t;
+            { // the back image from the origin to the front's first hit: in one walk, or -- the cooperative kernel's second pass --
+              // cut into `parts` intervals of [0, front hit], every walk bounded by the front hit
+                const float limit = best;
+                if (parts <= 1)
+                    best = ok_cast_poly_interval<true, false>(vb, ox[i], oy[i], c, s, 0.0F, OKRC_INF, &tests, &cells, &points, nullptr, false, limit).min_t;
+                else
+                {
+                    const float dt = limit / (float)parts;
+                    for (int j = 0; j < parts; ++j)
+                    {
+                        const float ta = (float)j * dt, tb = (j == parts - 1) ? OKRC_INF : (float)(j + 1) * dt;
+                        const float tj = ok_cast_poly_interval<true, false>(vb, ox[i], oy[i], c, s, ta, tb, &tests, &cells, &points, nullptr, j > 0, limit).min_t;
+                        best           = tj < best ? tj : best;
+                    }
+                }
                 flags |= 4U;
             }
             out_t[i] = best;

@@ -135,7 +135,7 @@ def test_split_gives_the_sweeps_first_hit(gridcheck, oracle, track_name, cell, p
     assert bad.size == 0 and collinear <= 2, (bad[:5], got[bad[:5]], ref[bad[:5]], fl[bad[:5]], ox[bad[:5]], oy[bad[:5]], ang[bad[:5]])
     # the population is what it was made to be: certified and uncertified origins, ambiguous walks, all in numbers
     cert, amb, backw = (fl & 1) != 0, (fl & 2) != 0, (fl & 4) != 0
-    assert 0.2 < cert.mean() < 0.9 and amb.sum() > 10 and (backw == (~cert | amb)).all()
+    assert 0.2 < cert.mean() < 0.9 and (amb & cert).sum() > 3 and (backw == (~cert | amb)).all()
     # and every ray through the back image as well: front + back is the whole set
     got2, _, _, _ = cast_fb(gridcheck, t, cell, ox, oy, ang, parts, force_back=1)
     assert mismatches(t, ox, oy, ang, got2, ref)[0].size == 0

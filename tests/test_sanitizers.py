@@ -48,11 +48,11 @@ def test_facade_host_code_under_asan_ubsan(tmp_path):
 def test_oracle_and_grid_walk_under_asan_ubsan():
     """The ordinary CPU parity tests on the instrumented oracle and the instrumented product headers: golden trajectory (kinematics,
     standstill, raycast, epilogue), known-answer rays, the grid walk against the brute-force sweep with adversarial rays, interval
-    splits and the division-free exact test, device-side resetAgent's restatement."""
+    splits and the division-free exact test, the front / back split of the segment set (classification, images, origin test)."""
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_oracle_raycast.py"),
                         os.path.join(ROOT, "tests", "test_golden.py") + "::test_oracle_reproduces_c1_trajectory_fixture",
-                        os.path.join(ROOT, "tests", "test_grid_traversal.py"), "-k",
+                        os.path.join(ROOT, "tests", "test_grid_traversal.py"), os.path.join(ROOT, "tests", "test_front_back_split.py"), "-k",
                         "not Silverstone and not Spa"],
                        capture_output=True, text=True, timeout=1500, cwd=ROOT, env=san_env())
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]

@@ -31,7 +31,7 @@ t = ok.Track("Monza")
 env = ok.BatchedEnvironment.from_track(t, 8192, 32)
 env.set(ok.capi.F_MODE, np.ones(8192, dtype=np.uint8))
 env.policy_mlp_create(30, 1234, 0)
-for g in range(2):
+for g in range(4):
     env.reset_all(float(t.x[3]), float(t.y[3]), float(t.heading[0]))
     env.step(1)
     episode(env, lambda n, s: env.rollout_policy(n), "c3 gen %d" % g)
