@@ -441,10 +441,7 @@ inline OkGridHost okBuildGridAuto(const OkSeg *segs,
         }
         if (num_segments * 8U + 64U > lds_budget)
             break; // the points alone do not fit: no cell size will help
-        if (image->ok)
-            cell *= 1.25F; // too big for LDS: fewer, larger cells
-        else
-            break; // more than 2^20 slots: the compact form cannot index them
+        cell *= 1.25F; // too big for LDS (or more slots than the headers can index): fewer, larger cells
     }
     *fits_lds = false;
     return okBuildGrid(segs, num_segments, requested > 0.F ? requested : OKGRID_DEFAULT_CELL);
@@ -489,7 +486,7 @@ struct OkFrontBack
 };
 #define OKFB_CELL_CERT 1U
 #define OKFB_CELL_CHI 2U
-#define OKFB_HDR_SHIFT 27 // the cell flags sit in bits 27..30 of the front image's header word w0
+#define OKFB_HDR_SHIFT OKFB_HDR_SHIFT_RC // the cell flags in the front image's header word w0 (ok_raycast.h), the F slot count above them
 
 namespace okgrid
 {
@@ -705,8 +702,7 @@ inline OkFrontBack okClassifyFrontBack(const OkSeg *segs, const size_t n, const 
             }
             if (any_front)
                 ++fb.n_cells_with_front;
-            if (!only_f)
-                continue;
+            (void)only_f; // (other front segments may share the cell: the image lists the F segments first and says how many slots they take)
             for (unsigned code = 0; code < 4U; ++code)
             {
                 float rx, ry;
@@ -765,6 +761,30 @@ inline OkFrontBackImages okBuildFrontBackImages(const OkSeg *segs, const size_t 
     if (out.grid_front.g.nx != grid.g.nx || out.grid_front.g.ny != grid.g.ny || out.grid_back.g.nx != grid.g.nx || out.grid_back.g.ny != grid.g.ny ||
         out.grid_front.g.x0 != grid.g.x0 || out.grid_front.g.y0 != grid.g.y0 || out.grid_front.g.cell != grid.g.cell)
         return out;
+    // the front image lists a cell's F segments first (the origin test looks at those and only those), the other front segments --
+    // outer pieces near the inner boundaries' swallowtails, segments of no closed chain -- behind them; chained runs never straddle the
+    // two groups (they belong to different chains)
+    std::vector<uint32_t> n_f_slots(grid.numCells(), 0U);
+    auto sameBits = [](const float a, const float b) {
+        uint32_t ua, ub;
+        std::memcpy(&ua, &a, 4);
+        std::memcpy(&ub, &b, 4);
+        return ua == ub;
+    };
+    for (size_t c = 0; c < grid.numCells(); ++c)
+    {
+        uint32_t *lo = out.grid_front.refs.data() + out.grid_front.start[c], *hi = out.grid_front.refs.data() + out.grid_front.start[c + 1];
+        uint32_t *mid = std::stable_partition(lo, hi, [&](const uint32_t sidx) { return fb.chi_def[sidx] != 0; });
+        // slots the F part takes: a run of r chained segments = r + 1 points (okBuildPolyImage's rule)
+        for (uint32_t *q = lo; q < mid;)
+        {
+            uint32_t r = 1;
+            while (q + r < mid && q[r] == q[0] + r && sameBits(segs[q[0] + r].x1, segs[q[0] + r - 1].x2) && sameBits(segs[q[0] + r].y1, segs[q[0] + r - 1].y2))
+                ++r;
+            n_f_slots[c] += r + 1U;
+            q += r;
+        }
+    }
     out.front = okBuildPolyImage(segs, n, out.grid_front);
     out.back  = okBuildPolyImage(segs, n, out.grid_back);
     if (!out.front.ok || !out.back.ok)
@@ -773,12 +793,15 @@ inline OkFrontBackImages okBuildFrontBackImages(const OkSeg *segs, const size_t 
     fb.n_cells_cert = 0;
     for (size_t c = 0; c < grid.numCells(); ++c)
     {
-        uint32_t flags = fb.cell_flags[c];
-        if (((hdr[c].w0 >> (OKPOLY_IDX_BITS + 6)) & 1U) != 0U) // the cell's front slots continue in a second chunk: not certifiable
+        uint32_t       flags    = fb.cell_flags[c];
+        const uint32_t n_first  = (hdr[c].w0 >> OKPOLY_IDX_BITS) & OKPOLY_N_MASK;
+        const bool     has_next = ((hdr[c].w0 >> (OKPOLY_IDX_BITS + 6)) & 1U) != 0U;
+        // the F slots must all sit in the cell's first chunk (a chunk that continues ends on a point the next one repeats)
+        if (n_f_slots[c] > (has_next ? n_first - 1U : n_first) || n_f_slots[c] > 32U)
             flags = 0U;
         fb.cell_flags[c] = static_cast<uint8_t>(flags);
         fb.n_cells_cert += (flags & OKFB_CELL_CERT) ? 1U : 0U;
-        hdr[c].w0 |= flags << OKFB_HDR_SHIFT;
+        hdr[c].w0 |= (flags << OKFB_HDR_SHIFT) | ((flags & OKFB_CELL_CERT) ? (n_f_slots[c] << OKFB_HDR_NF_SHIFT) : 0U);
     }
     out.ok = true;
     return out;

@@ -86,7 +86,8 @@ struct OkGridView32
 // boundary points and an 8-byte header per cell).
 struct OkCellHdr
 {
-    uint32_t w0;  // first_slot (20 bits) | n_slots << 20 (6 bits, even, <= 32) | has_next << 26
+    uint32_t w0;  // first_slot (15 bits: an image that fits the 160 KB of LDS has < 20 480 slots) | n_slots << 15 (6 bits, even, <= 32) |
+                  // has_next << 21 | front / back split, front image only: cell flags << 22 (4 bits) | slots of F segments << 26 (6 bits)
     uint32_t brk; // break bits, in the point loop's accumulator order: with n8 = n_slots rounded up to 8, bit (n8 - 1 - j) is
                   // set when NO segment joins slots first_slot + j - 1 and first_slot + j (j = 0, run starts, padding, every
                   // j >= n_slots); the bits from n8 on are set too
@@ -106,8 +107,8 @@ struct OkPolyView
     // arithmetic missed and is reported as ambiguous
     float            e_s, e_t, e_s_over_e_t;
 };
-#define OKPOLY_IDX_BITS 20
-#define OKPOLY_IDX_MASK 0xFFFFFU
+#define OKPOLY_IDX_BITS 15
+#define OKPOLY_IDX_MASK 0x7FFFU
 #define OKPOLY_MAX_SLOTS 32U
 #define OKPOLY_N_MASK 0x3FU
 
@@ -453,7 +454,9 @@ OKRC_HD uint32_t okCountTrailingZeros(const uint32_t x)
 // segments that the straight line from the reference point to the origin crosses.  Both points lie in the cell, so only segments
 // registered in the cell can be crossed, and in a certifiable cell every front segment IS an F segment: the pairs of the cell's
 // (single) front chunk are all there is to test.
-#define OKFB_HDR_SHIFT_RC 27 // = OKFB_HDR_SHIFT in ok_grid.h: cell flags in the front image's header word w0
+#define OKFB_HDR_SHIFT_RC (OKPOLY_IDX_BITS + 7) // cell flags in the front image's header word w0: certifiable, chi(ref), ref code (2 bits)
+#define OKFB_HDR_NF_SHIFT (OKPOLY_IDX_BITS + 11) // ... and above them the number of the cell's slots that belong to F segments: they come
+                                                 // first in the cell's (first) chunk, whatever other front segments follow them
 #define OKFB_RC_CERT 1U
 #define OKFB_RC_CHI 2U
 
@@ -502,7 +505,7 @@ OKRC_HD int okOriginChiScalar(const OkPolyView &front, const float ox, const flo
     ix     = ix < 0 ? 0 : (ix >= g.nx ? g.nx - 1 : ix);
     iy     = iy < 0 ? 0 : (iy >= g.ny ? g.ny - 1 : iy);
     const OkCellHdr hc    = front.hdr[iy * g.nx + ix];
-    const uint32_t  flags = hc.w0 >> OKFB_HDR_SHIFT_RC;
+    const uint32_t  flags = (hc.w0 >> OKFB_HDR_SHIFT_RC) & 15U;
     if ((flags & OKFB_RC_CERT) == 0U)
         return 0;
     float rx, ry;
@@ -510,8 +513,9 @@ OKRC_HD int okOriginChiScalar(const OkPolyView &front, const float ox, const flo
     const uint32_t k0 = hc.w0 & OKPOLY_IDX_MASK;
     const uint32_t n  = (hc.w0 >> OKPOLY_IDX_BITS) & OKPOLY_N_MASK;
     const uint32_t n8 = (n + 7U) & ~7U;
+    const uint32_t nf = hc.w0 >> OKFB_HDR_NF_SHIFT; // the chunk's first nf slots are the F segments' (<= n)
     uint32_t       parity = (flags & OKFB_RC_CHI) ? 1U : 0U;
-    for (uint32_t j = 0; j + 1U < n; ++j)
+    for (uint32_t j = 0; j + 1U < nf; ++j)
     { // pair (slot j, slot j + 1) is a segment when the break bit of slot j + 1 is clear (bit n8 - 1 - (j + 1))
         if ((hc.brk >> (n8 - 2U - j)) & 1U)
             continue;

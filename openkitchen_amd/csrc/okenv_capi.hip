@@ -925,7 +925,10 @@ extern "C"
         // Silverstone / Spa x 64 rays 4 % faster at 24, Monza x 32 rays 6 % faster at 20)
         // (round 3: 16-ray fans four to a wave -- BASELINE config 5 -- 24 px cells with a 32 px phase 1: 15.6 against 16.4 us per step)
         const bool  narrow16     = h->G == 16 && h->rays_per_lane == 1;
-        const float cell_default = ((h->G == 64 && h->rays_per_lane == 1 && num_rays > 32) || narrow16) ? 24.F : OKGRID_DEFAULT_CELL;
+        // (wide fans, one agent per wave: 28 px since the front / back split halved the points per cell -- 9.5-10.0 us per C2 step at
+        // 28-30 px against 10.4 at 24 and 10.7 at 20, profiles/r4/front_back_ab.txt; 16-ray fans stay at 24, 32-ray fans at 20)
+        const bool  wide64       = h->G == 64 && h->rays_per_lane == 1 && num_rays > 32;
+        const float cell_default = wide64 ? 28.F : (narrow16 ? 24.F : OKGRID_DEFAULT_CELL);
         if (narrow16)
             h->phase1_range = 32.F;
         h->grid = okBuildGridAuto(segs, static_cast<size_t>(num_segments), grid_cell > 0.F ? grid_cell : cell_default, kLdsBudget - kLdsReserve,

@@ -882,13 +882,13 @@ __device__ __forceinline__ bool okOriginChiGroup(const OkPolyView &front, const 
     ix                       = ix < 0 ? 0 : (ix >= g.nx ? g.nx - 1 : ix);
     iy                       = iy < 0 ? 0 : (iy >= g.ny ? g.ny - 1 : iy);
     const OkCellHdr hc       = front.hdr[inside ? iy * g.nx + ix : 0];
-    const uint32_t  flags    = hc.w0 >> OKFB_HDR_SHIFT_RC;
+    const uint32_t  flags    = (hc.w0 >> OKFB_HDR_SHIFT_RC) & 15U;
     const bool      usable   = inside && (flags & OKFB_RC_CERT) != 0U;
     float           rx, ry;
     okCellRefPoint(g, ix, iy, (flags >> 2) & 3U, &rx, &ry);
     const uint32_t k0 = hc.w0 & OKPOLY_IDX_MASK;
-    const uint32_t n  = usable ? ((hc.w0 >> OKPOLY_IDX_BITS) & OKPOLY_N_MASK) : 0U;
-    const uint32_t n8 = (n + 7U) & ~7U;
+    const uint32_t n8 = (((hc.w0 >> OKPOLY_IDX_BITS) & OKPOLY_N_MASK) + 7U) & ~7U;
+    const uint32_t n  = usable ? (hc.w0 >> OKFB_HDR_NF_SHIFT) : 0U; // the slots of the cell's F segments: the first of its chunk
     bool           amb = false, odd = false;
     // distance to the cell's border (the cell's corners in the walk's own arithmetic)
     const float cx0 = g.x0 + static_cast<float>(ix) * g.cell, cy0 = g.y0 + static_cast<float>(iy) * g.cell;
