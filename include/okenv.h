@@ -130,6 +130,11 @@ typedef struct okenv_info {
  * (x1,y1,x2,y2); `ray_angles_deg` is Agent::sensor_ray_angles_ (all agents share one fan,
  * CollisionChecker.cu:82).  All state starts zeroed (mode VELOCITY, not crashed).
  * `grid_cell` <= 0 selects the default cell edge.
+ * A segment set in TrackSegments order whose boundary polylines close (every track the reference builds) is additionally split
+ * into the segments a ray from between the inner boundaries can hit first and the rest (the outer polylines, 3 px behind the
+ * inner ones): the step kernels look at the rest only for rays whose origin is not certified to lie between the inner boundaries
+ * -- same first hit, bit for bit, about half the points per ray (okenv_info.front_back_bytes / back_segments,
+ * okenv_work_stats_split; environment variable OKENV_FRONT_BACK=0 switches it off).  Any other segment set is stepped as before.
  */
 OKENV_API int okenv_create(okenv_t *out, const float *segments_xyxy, int32_t num_segments, int32_t num_agents,
                            int32_t num_rays, const float *ray_angles_deg, int32_t device, uint32_t flags,
