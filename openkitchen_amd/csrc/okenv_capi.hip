@@ -939,6 +939,54 @@ extern "C"
             h->grid_mode = kGridGlobal;
         else
             h->grid_mode = kGridLds;
+        // The front / back split (ok_grid.h): the outer boundary polylines in an image of their own, walked only by the rays that
+        // need it.  OKENV_FRONT_BACK=0 keeps every launch on the combined image (ablation; same results).
+        const char *env_fb = std::getenv("OKENV_FRONT_BACK");
+        if (h->grid_mode == kGridLds && (env_fb == nullptr || std::atoi(env_fb) != 0))
+        {
+            auto classify = [&]() {
+                h->fbc = okClassifyFrontBack(segs, static_cast<size_t>(num_segments), h->grid, h->poly.max_seg_len);
+                h->fbi = okBuildFrontBackImages(segs, static_cast<size_t>(num_segments), h->grid, h->fbc);
+            };
+            classify();
+            // 32-lane groups (the EvolutionaryRacer shape): most of a generation's steps are taken by the tail kernel, one agent per
+            // workgroup, and the drivers hand a list over to it at up to two workgroups per CU -- which the two images allow only when
+            // they fit the CU's LDS twice.  With a default cell edge the smallest of 20 / 24 / 28 / 32 px that manages it is taken
+            // (larger cells, smaller images; the cooperative kernel's step time is flat over that range: profiles/r4/front_back_ab.txt).
+            const size_t tail_extra = 16U + sizeof(float) * kTailLdsFloats;
+            auto twice = [&]() { return 2U * (h->fbi.front.bytes.size() + h->fbi.back.bytes.size() + tail_extra) <= kLdsBudget; };
+            if (grid_cell <= 0.F && h->G == 32 && h->fbi.ok && !twice())
+            {
+                const OkGridHost       grid0 = h->grid;
+                const OkPolyImage      poly0 = h->poly;
+                const OkFrontBack      fbc0  = h->fbc;
+                const OkFrontBackImages fbi0 = h->fbi;
+                bool                   found = false;
+                for (const float c : {24.F, 28.F, 32.F})
+                {
+                    bool        fits2 = false;
+                    OkPolyImage poly2;
+                    OkGridHost  grid2 = okBuildGridAuto(segs, static_cast<size_t>(num_segments), c, kLdsBudget - kLdsReserve, &fits2, &poly2);
+                    if (!fits2)
+                        break;
+                    h->grid = grid2;
+                    h->poly = poly2;
+                    classify();
+                    if (h->fbi.ok && twice())
+                    {
+                        found = true;
+                        break;
+                    }
+                }
+                if (!found)
+                {
+                    h->grid = grid0;
+                    h->poly = poly0;
+                    h->fbc  = fbc0;
+                    h->fbi  = fbi0;
+                }
+            }
+        }
 
         int rc;
         if ((rc = devAlloc(h, &h->d_segs, static_cast<size_t>(num_segments))) != OKENV_OK)
@@ -953,24 +1001,17 @@ extern "C"
                 return fail(nullptr, rc, h->last_error);
             h->d_image = dimg;
             OK_HIP(nullptr, hipMemcpyAsync(dimg, img.data(), h->image_bytes, hipMemcpyHostToDevice, h->stream));
-            // The front / back split (ok_grid.h): the outer boundary polylines in an image of their own, walked only by the rays
-            // that need it.  OKENV_FRONT_BACK=0 keeps every launch on the combined image (ablation; same results).
-            const char *env_fb = std::getenv("OKENV_FRONT_BACK");
-            if (env_fb == nullptr || std::atoi(env_fb) != 0)
+            // The front / back split (ok_grid.h; classified before the images were uploaded, above): its two images as one blob.
+            if (h->fbi.ok && h->fbi.front.bytes.size() + h->fbi.back.bytes.size() <= kLdsBudget - kLdsReserve)
             {
-                h->fbc = okClassifyFrontBack(segs, static_cast<size_t>(num_segments), h->grid, h->poly.max_seg_len);
-                h->fbi = okBuildFrontBackImages(segs, static_cast<size_t>(num_segments), h->grid, h->fbc);
-                if (h->fbi.ok && h->fbi.front.bytes.size() + h->fbi.back.bytes.size() <= kLdsBudget - kLdsReserve)
-                {
-                    h->fb_back_off = h->fbi.front.bytes.size(); // (a multiple of 16: both parts of an image are 16-byte aligned)
-                    h->fb_bytes    = h->fb_back_off + h->fbi.back.bytes.size();
-                    if ((rc = devAlloc(h, &h->d_image_fb, h->fb_bytes)) != OKENV_OK)
-                        return fail(nullptr, rc, h->last_error);
-                    OK_HIP(nullptr, hipMemcpyAsync(h->d_image_fb, h->fbi.front.bytes.data(), h->fb_back_off, hipMemcpyHostToDevice, h->stream));
-                    OK_HIP(nullptr, hipMemcpyAsync(h->d_image_fb + h->fb_back_off, h->fbi.back.bytes.data(), h->fbi.back.bytes.size(), hipMemcpyHostToDevice,
-                                                   h->stream));
-                    h->fb_ok = true;
-                }
+                h->fb_back_off = h->fbi.front.bytes.size(); // (a multiple of 16: both parts of an image are 16-byte aligned)
+                h->fb_bytes    = h->fb_back_off + h->fbi.back.bytes.size();
+                if ((rc = devAlloc(h, &h->d_image_fb, h->fb_bytes)) != OKENV_OK)
+                    return fail(nullptr, rc, h->last_error);
+                OK_HIP(nullptr, hipMemcpyAsync(h->d_image_fb, h->fbi.front.bytes.data(), h->fb_back_off, hipMemcpyHostToDevice, h->stream));
+                OK_HIP(nullptr, hipMemcpyAsync(h->d_image_fb + h->fb_back_off, h->fbi.back.bytes.data(), h->fbi.back.bytes.size(), hipMemcpyHostToDevice,
+                                               h->stream));
+                h->fb_ok = true;
             }
             OK_HIP(nullptr, hipStreamSynchronize(h->stream));
             const int lds_plain = static_cast<int>(h->image_bytes);
