@@ -46,9 +46,10 @@ def algorithmic_bytes_per_agent_step(N, R, S):
 
 
 # everything the profiled kernel's behaviour depends on: the kernels, the walk, the grid builder, the launch geometry and defaults
-# (cell edge, phase-1 range, block / grid sizes, tail limits: okenv_capi.hip), the shared math (sincos, Philox) and the ABI
+# (cell edge, phase-1 range, block / grid sizes, tail limits: okenv_capi.hip) and the shared math (sincos, Philox).  (include/okenv.h is
+# declarations and comments: what it declares is defined, and would change, in okenv_capi.hip)
 KERNEL_SOURCES = ["openkitchen_amd/csrc/okenv_kernels.h", "openkitchen_amd/csrc/ok_raycast.h", "openkitchen_amd/csrc/ok_grid.h",
-                  "openkitchen_amd/csrc/okenv_capi.hip", "include/okenv_math.h", "include/okenv.h"]
+                  "openkitchen_amd/csrc/okenv_capi.hip", "include/okenv_math.h"]
 
 
 def kernel_source_hash(root=ROOT):
