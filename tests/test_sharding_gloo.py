@@ -1,4 +1,4 @@
-"""N>1 path on CPU: two processes over gloo.  The shard engines are oracle-backed stand-ins (tests only); what is under
+"""N>1 path on CPU: two (and four) processes over gloo.  The shard engines are oracle-backed stand-ins (tests only); what is under
 test is the product's sharding logic (openkitchen_amd/sharding.py): global agent ids per rank, the fitness all-gather's
 layout, max-over-ranks timing -- and that a sharded population reproduces the unsharded one."""
 import os
@@ -8,6 +8,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -55,13 +56,14 @@ WORKER = textwrap.dedent('''
             sums[700:] = np.finfo(np.float32).min; counts[700:] = 0      # entries nobody has visited
             return sums, counts
         def q_assign_mean(self, sums, counts): self.got = (sums.copy(), counts.copy())
-        def q_share_knowledge(self): raise AssertionError("single-process path taken with world size 2")
+        def q_share_knowledge(self): raise AssertionError("single-process path taken with a process group")
     q = QStub()
     sharding.share_q_knowledge(q)
     sums, counts = q.got
-    want_s = np.full(729, 3.0, dtype=np.float32); want_c = np.full(729, 4.0, dtype=np.float32)
-    want_s[0], want_c[0] = 2.0, 2.0    # only rank 1 contributed
-    want_s[1], want_c[1] = 1.0, 2.0    # only rank 0 contributed
+    total = world * (world + 1) / 2.0
+    want_s = np.full(729, total, dtype=np.float32); want_c = np.full(729, 2.0 * world, dtype=np.float32)
+    for r in range(world):             # entry r: every rank but r contributed
+        want_s[r], want_c[r] = total - (1.0 + r), 2.0 * (world - 1)
     want_s[700:], want_c[700:] = np.finfo(np.float32).min, 0.0
     assert np.array_equal(sums, want_s) and np.array_equal(counts, want_c)
     if rank == 0:
@@ -79,22 +81,25 @@ def free_port():
     return p
 
 
-def test_two_rank_gloo_population_matches_unsharded(oracle, tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_ranks_population_matches_unsharded(oracle, tmp_path, world):
     out = str(tmp_path / "fitness.npy")
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT, "out": out})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
                     "--master-port", str(free_port()), str(script)], check=True, env=env, timeout=600, cwd=ROOT)
     fit = np.load(out)
+    assert fit.shape == (world, 12)
     # the same population, unsharded, through the oracle
+    n = 12 * world
     t = oracle.Track("Austin")
-    env1 = oracle.OracleEnv(t.segments, 24, 8, oracle.default_ray_fan(8), (t.x, t.y, t.heading))
+    env1 = oracle.OracleEnv(t.segments, n, 8, oracle.default_ray_fan(8), (t.x, t.y, t.heading))
     env1.init_bench_state(0, 0)
     env1.rollout_random(60, 99, 0, 0)
     s = env1.snapshot()
-    want = np.zeros(24, dtype=np.int32)
-    oracle.lib().oracle_nearest_track_idx(t.x, t.y, t.P, s["pos_x"], s["pos_y"], 24, want)
+    want = np.zeros(n, dtype=np.int32)
+    oracle.lib().oracle_nearest_track_idx(t.x, t.y, t.P, s["pos_x"], s["pos_y"], n, want)
     assert np.array_equal(fit.reshape(-1).astype(np.int32), want)
 
 
