@@ -62,7 +62,7 @@ struct Options
 
 bool parse(int argc, char **argv, Options &o)
 {
-    if (argc < 2)
+    if (argc < 2 || (argc - 2) % 2 != 0) // (every option takes a value)
         return false;
     o.track = argv[1];
     for (int i = 2; i + 1 < argc; i += 2)
@@ -217,6 +217,11 @@ void runIsland(Colony &c, const int g)
     const float start_x = c.cx[3], start_y = c.cy[3], start_rot = c.heading[0];
     const std::string suffix = K > 1 && g > 0 ? ".island" + std::to_string(g) : "";
     std::FILE *dump = opt.dump.empty() ? nullptr : std::fopen((opt.dump + (K > 1 ? ".island" + std::to_string(g) : "")).c_str(), "wb");
+    if (!opt.dump.empty() && dump == nullptr)
+    {
+        std::fprintf(stderr, "island %d: cannot write %s\n", g, opt.dump.c_str());
+        std::quick_exit(2);
+    }
     std::vector<float> colony_avg_scores;
     float              prev_gen_best_score = 0.F, top_score_all_time = 0.F;
     std::vector<float> best_weights;

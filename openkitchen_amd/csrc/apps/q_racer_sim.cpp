@@ -34,7 +34,7 @@ struct Options
 
 bool parse(int argc, char **argv, Options &o)
 {
-    if (argc < 2)
+    if (argc < 2 || (argc - 2) % 2 != 0) // (every option takes a value)
         return false;
     o.track = argv[1];
     for (int i = 2; i + 1 < argc; i += 2)
@@ -104,6 +104,11 @@ int main(int argc, char **argv)
     CHECK(okenv_q_create(env));
 
     std::FILE *dump        = opt.dump.empty() ? nullptr : std::fopen(opt.dump.c_str(), "wb");
+    if (!opt.dump.empty() && dump == nullptr)
+    {
+        std::fprintf(stderr, "cannot write %s\n", opt.dump.c_str());
+        return 2;
+    }
     float      epsilon     = 0.9F;  // QAgent.hpp:26
     const float kEpsilonDiscount = 0.05F; // QAgent.hpp:27
     int32_t    reset_idx   = 3;     // RaceTrack::kStartingIdx (q_racer_sim.cpp:114)
