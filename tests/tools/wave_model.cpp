@@ -17,6 +17,9 @@
 namespace
 {
 double g_cls[5] = {0, 0, 0, 0, 0};
+int    g_front_only = 0; // walk the FRONT image of the front / back split (ok_grid.h) instead of the combined one
+int    g_no_early_stop = 0; // mock-up of deferred exact tests: a walk does not end on a hit inside the covered part (its exact tests are
+                           // still pending then), only at the end of its interval, of the range or of the grid
 struct ChunkRec
 {
     uint16_t pairs;  // point-pair iterations of the chunk
@@ -128,7 +131,7 @@ LaneTrace traceInterval(const OkPolyView &v, float ox, float oy, float rdx, floa
         tr.cells.push_back(cr);
         const float t_exit = w.exitT();
         tr.min_t           = min_t;
-        if (__builtin_fminf(min_t, w.t_out) <= t_exit)
+        if (__builtin_fminf(g_no_early_stop ? OKRC_INF : min_t, w.t_out) <= t_exit)
         {
             tr.t_reached  = t_exit;
             tr.conclusive = true;
@@ -137,7 +140,7 @@ LaneTrace traceInterval(const OkPolyView &v, float ox, float oy, float rdx, floa
         if (t_exit >= t_b || --max_cells <= 0)
         {
             tr.t_reached  = t_exit;
-            tr.conclusive = false;
+            tr.conclusive = min_t <= t_exit; // (deferred tests: known after the flush at the end of the walk)
             return tr;
         }
         if (!w.advance(g))
@@ -163,8 +166,77 @@ struct WaveCount
     double half_it = 0;                                                      // point loop in rounds of FOUR slots
     double pooled_it = 0;                                                    // exact loop if a chunk's candidates were pooled over the wave's lanes
     double cell_lanes = 0, chunk_lanes = 0, pair_lanes = 0, exact_lanes = 0; // active lane-iterations
+    // exact loop with DEFERRED tests: a lane parks a chunk's candidates (queue of 1 or 2 chunks) and tests them when the queue is
+    // full and another chunk with candidates arrives, or when its walk ends; a flush is a lock-step loop over the flushing lanes
+    double defer1_it = 0, defer2_it = 0;
+    void   addDeferred(const std::vector<LaneTrace> &lanes)
+    {
+        for (int depth = 1; depth <= 2; ++depth)
+        {
+            double                        &acc = depth == 1 ? defer1_it : defer2_it;
+            std::vector<std::vector<int>>  q(lanes.size());
+            size_t max_cells = 0;
+            for (auto &l : lanes)
+                max_cells = std::max(max_cells, l.cells.size());
+            for (size_t c = 0; c < max_cells; ++c)
+            {
+                size_t max_chunks = 0;
+                for (auto &l : lanes)
+                    if (c < l.cells.size())
+                        max_chunks = std::max(max_chunks, l.cells[c].chunks.size());
+                for (size_t k = 0; k < max_chunks; ++k)
+                {
+                    int flush = 0;
+                    for (size_t i = 0; i < lanes.size(); ++i)
+                    {
+                        const auto &l = lanes[i];
+                        if (!(c < l.cells.size() && k < l.cells[c].chunks.size()) || l.cells[c].chunks[k].exact == 0)
+                            continue;
+                        if (static_cast<int>(q[i].size()) == depth)
+                        { // queue full: the oldest chunk's candidates are tested now
+                            flush = std::max(flush, q[i].front());
+                            q[i].erase(q[i].begin());
+                        }
+                        q[i].push_back(l.cells[c].chunks[k].exact);
+                    }
+                    acc += flush;
+                }
+                // lanes whose walk ends with this cell flush what they hold (they have to report); the others' queues stay
+                int flush_end = 0;
+                for (size_t i = 0; i < lanes.size(); ++i)
+                    if (c + 1 == lanes[i].cells.size())
+                    {
+                        int tot = 0;
+                        for (int e : q[i])
+                            tot += e;
+                        flush_end = std::max(flush_end, tot);
+                        q[i].clear();
+                    }
+                // (ends of different lanes fall into different cell iterations; a lane that ended waits, so the flushes of all lanes
+                // that end within the same iteration run together -- and a smarter kernel would hold them until the LAST lane ends)
+                acc += flush_end;
+            }
+        }
+    }
+    // the same with every lane holding everything until the wave's last lane has ended: one flush per walk phase
+    double defer_all_it = 0;
+    void   addDeferredAll(const std::vector<LaneTrace> &lanes)
+    {
+        int m = 0;
+        for (auto &l : lanes)
+        {
+            int tot = 0;
+            for (auto &c : l.cells)
+                for (auto &k : c.chunks)
+                    tot += k.exact;
+            m = std::max(m, tot);
+        }
+        defer_all_it += m;
+    }
     void   add(const std::vector<LaneTrace> &lanes)
     {
+        addDeferred(lanes);
+        addDeferredAll(lanes);
         size_t max_cells = 0;
         for (auto &l : lanes)
             max_cells = std::max(max_cells, l.cells.size());
@@ -208,6 +280,12 @@ struct WaveCount
 };
 } // namespace
 
+extern "C" __attribute__((visibility("default"))) void wavemodel_set_options(int front_only, int no_early_stop)
+{
+    g_front_only    = front_only;
+    g_no_early_stop = no_early_stop;
+}
+
 extern "C" __attribute__((visibility("default"))) void wavemodel_set_p2_mode(int mode, int cells_goal, int p1_max_cells)
 {
     g_p2_mode      = mode;
@@ -239,6 +317,19 @@ extern "C" __attribute__((visibility("default"))) int wavemodel_run(const float 
     pv.slots    = reinterpret_cast<const OkPoint *>(img.bytes.data());
     pv.hdr      = reinterpret_cast<const OkCellHdr *>(img.bytes.data() + img.off_hdr);
     pv.side_tol = img.side_tol;
+    OkFrontBack       fbc;
+    OkFrontBackImages fbi;
+    if (g_front_only)
+    {
+        fbc = okClassifyFrontBack(segs, static_cast<size_t>(S), gh, img.max_seg_len);
+        fbi = okBuildFrontBackImages(segs, static_cast<size_t>(S), gh, fbc);
+        if (!fbi.ok)
+            return -2;
+        pv.g        = fbi.grid_front.g;
+        pv.slots    = reinterpret_cast<const OkPoint *>(fbi.front.bytes.data());
+        pv.hdr      = reinterpret_cast<const OkCellHdr *>(fbi.front.bytes.data() + fbi.front.off_hdr);
+        pv.side_tol = fbi.front.side_tol;
+    }
     WaveCount p1, p2;
     for (double &x : g_cls) x = 0;
     double    n_pending = 0, waves_with_p2 = 0;
@@ -335,6 +426,8 @@ extern "C" __attribute__((visibility("default"))) int wavemodel_run(const float 
                 p1.half_it / W, p2.half_it / W, p1.half_it / W / 2, p2.half_it / W / 2);
     std::printf("    exact loop if a chunk's candidates were pooled over the 64 lanes: %.2f + %.2f passes (now %.2f + %.2f)\n", p1.pooled_it / W, p2.pooled_it / W,
                 p1.exact_it / W, p2.exact_it / W);
+    std::printf("    exact loop with deferred tests (%s early stop): queue of one chunk %.2f + %.2f, of two %.2f + %.2f, one flush per phase %.2f + %.2f passes\n",
+                g_no_early_stop ? "walks WITHOUT" : "walks with", p1.defer1_it / W, p2.defer1_it / W, p1.defer2_it / W, p2.defer2_it / W, p1.defer_all_it / W, p2.defer_all_it / W);
     if (g_p2_mode == 1)
         std::printf("    phase-2 rounds per wave-step: %.2f\n", g_p2_rounds / W);
     g_p2_rounds = 0;

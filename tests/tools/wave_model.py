@@ -57,15 +57,23 @@ def main():
         return
     hdr = ("(pairs column = 8-slot rounds)\ncell  T1 split pb |  p1: cells chunks pairs exact (util: cell pair exact) |  p2: cells chunks pairs exact (util) | pend  p2frac | image")
     print(hdr)
-    mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-    goal = int(sys.argv[5]) if len(sys.argv) > 5 else 0
-    p1cap = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    nums = [a for a in sys.argv[4:] if a.lstrip("-").isdigit()]
+    mode = int(nums[0]) if len(nums) > 0 else 0
+    goal = int(nums[1]) if len(nums) > 1 else 0
+    p1cap = int(nums[2]) if len(nums) > 2 else 0
     L.wavemodel_set_p2_mode(mode, goal, p1cap)
     print("phase 1 capped at %d cells" % p1cap if p1cap else "phase 1 ends at its range")
     print("cells per round and ray (goal): %d" % goal)
     print("phase 2: %s" % {0: "equal parameter intervals, start cells owned by one walk (shipped)", 1: "cell tasks (lane j of a ray takes cells after phase 1; rounds until done)",
                            2: "equal parameter intervals, every walk processes every cell it touches (round 2)"}[mode])
-    for cell, t1, split, pb in [(20, 48, 8, 1), (24, 48, 8, 1), (24, 40, 8, 1), (24, 32, 8, 1), (24, 24, 8, 1), (24, 56, 8, 1), (24, 200, 8, 1), (28, 48, 8, 1)]:
+    # further options: "front" = walk the front image of the front / back split; "nostop" = walks do not end on a hit (mock-up of
+    # deferred exact tests: what the point loop then costs, against the passes the exact loop saves)
+    front = 1 if "front" in sys.argv[4:] else 0
+    nostop = 1 if "nostop" in sys.argv[4:] else 0
+    L.wavemodel_set_options(front, nostop)
+    print("image: %s; walks %s" % ("front segments only" if front else "all segments", "do not end on a hit" if nostop else "end on a hit inside the covered part"))
+    for cell, t1, split, pb in ([(28, 48, 8, 1), (28, 32, 8, 1), (28, 64, 8, 1)] if front else
+                                [(20, 48, 8, 1), (24, 48, 8, 1), (24, 40, 8, 1), (24, 32, 8, 1), (24, 24, 8, 1), (24, 56, 8, 1), (24, 200, 8, 1), (28, 48, 8, 1)]):
         out = np.zeros(20)
         rc = L.wavemodel_run(track.segments, track.S, float(cell), px, py, rot, px.size, fan, R, float(t1), split, pb, out)
         if rc != 0:
