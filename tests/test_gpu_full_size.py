@@ -248,3 +248,38 @@ def test_c4_island_generation_that_runs_into_the_step_cap(gpu, oracle):
     assert np.array_equal(score[ids], og.scores())
     assert (want["crashed"] == 0).sum() == 1
     env.close()
+
+
+@pytest.mark.parametrize("N,R,track_name", [(10007, 64, "Silverstone"), (20011, 16, "Austin"), (9001, 32, "Monza")])
+def test_populations_beyond_one_round_of_workgroups_equal_oracle_windows(gpu, oracle, N, R, track_name):
+    """More agents than the machine holds at once (1.1 - 2.4 rounds of workgroups: the later ones queue behind the first) and a last
+    workgroup that is only partly filled: windows of the population -- its start, the seam between the first round and the
+    second, its very end -- against the oracle stepping those windows' global agent ids (agents are independent; the bench
+    driver's draws are keyed by the global id)."""
+    seed, W = 4321, 40
+    t = gpu.Track(track_name)
+    fan = gpu.default_ray_fan(R)
+    dev = gpu.BatchedEnvironment.from_track(t, N, num_rays=R)
+    info = dev.info()
+    lanes_per_round = info["compute_units"] * 1024
+    assert N * info["lanes_per_agent"] > lanes_per_round and info["grid_blocks"] > info["compute_units"]
+    assert (N * info["lanes_per_agent"]) % info["block_threads"] != 0  # the last workgroup is partly filled
+    seam = lanes_per_round // info["lanes_per_agent"]                   # first agent of the second round
+    bases = [0, seam - W // 2, N - W]
+    orcs = [oracle.OracleEnv(t.segments, W, R, fan, (t.x, t.y, t.heading)) for _ in bases]
+    dev.init_bench_state(0, 0)
+    for o, b in zip(orcs, bases):
+        o.init_bench_state(b, 0)
+    done = 0
+    for n in (1, 37, 100, 20):
+        dev.rollout_random(n, seed, 0, done)
+        for o, b in zip(orcs, bases):
+            o.rollout_random(n, seed, b, done, threads=8)
+        done += n
+        snap = dev.snapshot()
+        for o, b in zip(orcs, bases):
+            want = o.snapshot()
+            for k in FIELDS_EXACT:
+                assert np.array_equal(bits(snap[k][b:b + W]), bits(want[k])), (k, b, done)
+    assert (snap["crashed"] == 1).any() and snap["disp_ctr"].max() > 0
+    dev.close()
