@@ -18,6 +18,8 @@ namespace
 {
 double g_cls[5] = {0, 0, 0, 0, 0};
 int    g_front_only = 0; // walk the FRONT image of the front / back split (ok_grid.h) instead of the combined one
+float  g_predict_margin = 0.F; // > 0: phase 2 cuts [t_reached, last step's hit distance + margin] instead of [t_reached, range];
+                               // rays that do not end there get a second round over the rest (mock-up of a temporal prediction)
 int    g_no_early_stop = 0; // mock-up of deferred exact tests: a walk does not end on a hit inside the covered part (its exact tests are
                            // still pending then), only at the end of its interval, of the range or of the grid
 struct ChunkRec
@@ -158,7 +160,7 @@ LaneTrace traceInterval(const OkPolyView &v, float ox, float oy, float rdx, floa
 int g_p1_max_cells = 0; // phase 1 ends after this many cells at the latest (0: at its range only)
 int g_cells_goal = 0; // cell tasks: cells a round should cover per ray (0: one cell per lane)
 int g_p2_mode = 0; // 0: equal parameter intervals with the start-cell ownership rule (shipped), 2: without it (round 2), 1: cell tasks (lane j of a ray takes the j-th cell after t_reached), rounds until done
-double g_p2_rounds = 0;
+double g_p2_rounds = 0, g_second_round_rays = 0, g_second_round_waves = 0;
 
 struct WaveCount
 {
@@ -286,6 +288,11 @@ extern "C" __attribute__((visibility("default"))) void wavemodel_set_options(int
     g_no_early_stop = no_early_stop;
 }
 
+extern "C" __attribute__((visibility("default"))) void wavemodel_set_predict(float margin)
+{
+    g_predict_margin = margin;
+}
+
 extern "C" __attribute__((visibility("default"))) void wavemodel_set_p2_mode(int mode, int cells_goal, int p1_max_cells)
 {
     g_p2_mode      = mode;
@@ -392,6 +399,77 @@ extern "C" __attribute__((visibility("default"))) int wavemodel_run(const float 
                 pend.swap(next);
             }
         }
+        else if (!pend.empty() && g_predict_margin > 0.F)
+        {
+            waves_with_p2 += 1;
+            n_pending += pend.size();
+            // last step's distances: the same fan from a pose 1.2 px behind along the heading, turned by 2 degrees (what a step of
+            // the bench recipe changes at most)
+            float srp, crp;
+            ok_sincosf(OK_DEG2RAD * rot_deg[a], &srp, &crp);
+            const float pox = ox - 1.2F * crp, poy = oy - 1.2F * srp;
+            const int   n = static_cast<int>(pend.size());
+            int         m = 64 / n;
+            m             = m > max_split ? max_split : m;
+            std::vector<LaneTrace> l2;
+            std::vector<int>       next;
+            std::vector<float>     from(64, 0.F), best(64, OK_SENSOR_RANGE);
+            for (int q = 0; q < n; ++q)
+            {
+                const int r = pend[q];
+                float     pdx, pdy;
+                ok_sincosf(OK_DEG2RAD * (rot_deg[a] - 2.0F + ray_deg[r]), &pdy, &pdx);
+                const float d_prev = ok_cast_ray_poly<false>(pv, pox, poy, pdx, pdy, nullptr, nullptr, nullptr);
+                const float t0     = l1[r].t_reached;
+                const bool  open   = !(d_prev < OK_SENSOR_RANGE);
+                const float D      = open ? OK_SENSOR_RANGE : std::max(d_prev + g_predict_margin, t0 + 8.0F);
+                const float dt     = (D - t0) / static_cast<float>(m);
+                float       reached = t0;
+                bool        ended   = false;
+                best[r]             = l1[r].min_t;
+                for (int j = 0; j < m; ++j)
+                {
+                    const float ta = t0 + static_cast<float>(j) * dt;
+                    const float tb = (j + 1 == m && open) ? OKRC_INF : t0 + static_cast<float>(j + 1) * dt;
+                    LaneTrace   t  = traceInterval(pv, ox, oy, dx[r], dy[r], ta, tb, pair_batch, 0, 1 << 30, true);
+                    best[r]        = std::min(best[r], t.min_t);
+                    if (t.conclusive && t.t_reached >= OK_SENSOR_RANGE)
+                        ended = true;
+                    reached = std::max(reached, t.t_reached);
+                    l2.push_back(std::move(t));
+                }
+                if (!(ended || best[r] <= reached))
+                {
+                    next.push_back(r);
+                    from[r] = reached;
+                }
+            }
+            p2.add(l2);
+            g_p2_rounds += 1;
+            if (!next.empty())
+            { // second round: the rest of the rays whose hit was not where it had been, cut like today's phase 2
+                g_p2_rounds += 1;
+                const int n2 = static_cast<int>(next.size());
+                int       m2 = 64 / n2;
+                m2           = m2 > max_split ? max_split : m2;
+                std::vector<LaneTrace> l3;
+                for (int q = 0; q < n2; ++q)
+                {
+                    const int   r  = next[q];
+                    const float t0 = from[r];
+                    const float dt = (OK_SENSOR_RANGE - t0) / static_cast<float>(m2);
+                    for (int j = 0; j < m2; ++j)
+                    {
+                        const float ta = t0 + static_cast<float>(j) * dt;
+                        const float tb = (j + 1 == m2) ? OKRC_INF : t0 + static_cast<float>(j + 1) * dt;
+                        l3.push_back(traceInterval(pv, ox, oy, dx[r], dy[r], ta, tb, pair_batch, 0, 1 << 30, true));
+                    }
+                }
+                p2.add(l3);
+                g_second_round_rays += n2;
+                g_second_round_waves += 1;
+            }
+        }
         else if (!pend.empty())
         {
             waves_with_p2 += 1;
@@ -428,6 +506,10 @@ extern "C" __attribute__((visibility("default"))) int wavemodel_run(const float 
                 p1.exact_it / W, p2.exact_it / W);
     std::printf("    exact loop with deferred tests (%s early stop): queue of one chunk %.2f + %.2f, of two %.2f + %.2f, one flush per phase %.2f + %.2f passes\n",
                 g_no_early_stop ? "walks WITHOUT" : "walks with", p1.defer1_it / W, p2.defer1_it / W, p1.defer2_it / W, p2.defer2_it / W, p1.defer_all_it / W, p2.defer_all_it / W);
+    if (g_predict_margin > 0.F)
+        std::printf("    prediction (margin %g px): waves with a second round %.3f, rays in it per wave-step %.2f\n", g_predict_margin, g_second_round_waves / W,
+                    g_second_round_rays / W);
+    g_second_round_rays = g_second_round_waves = 0;
     if (g_p2_mode == 1)
         std::printf("    phase-2 rounds per wave-step: %.2f\n", g_p2_rounds / W);
     g_p2_rounds = 0;

@@ -71,6 +71,11 @@ def main():
     front = 1 if "front" in sys.argv[4:] else 0
     nostop = 1 if "nostop" in sys.argv[4:] else 0
     L.wavemodel_set_options(front, nostop)
+    predict = [a for a in sys.argv[4:] if a.startswith("predict=")]  # phase 2 cut at last step's hit distance + this margin [px]
+    if predict:
+        L.wavemodel_set_predict.argtypes = [C.c_float]
+        L.wavemodel_set_predict(float(predict[0].split("=")[1]))
+        print("phase 2 cut at the previous step's distance + %s px, second round for the rest" % predict[0].split("=")[1])
     print("image: %s; walks %s" % ("front segments only" if front else "all segments", "do not end on a hit" if nostop else "end on a hit inside the covered part"))
     for cell, t1, split, pb in ([(28, 48, 8, 1), (28, 32, 8, 1), (28, 64, 8, 1)] if front else
                                 [(20, 48, 8, 1), (24, 48, 8, 1), (24, 40, 8, 1), (24, 32, 8, 1), (24, 24, 8, 1), (24, 56, 8, 1), (24, 200, 8, 1), (28, 48, 8, 1)]):
